@@ -1,0 +1,84 @@
+"""ctypes binding of libdtp.so (include/dtp.h).  There is no fallback: if the HIP library is
+missing or an entry point fails, the caller gets an exception."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdtp.so")
+_lib = None
+
+
+class DtpError(RuntimeError):
+    pass
+
+
+class Settings(C.Structure):
+    _fields_ = [("steps", C.c_int), ("context_pad", C.c_int), ("tg_steps", C.c_int), ("cfg_weight", C.c_float),
+                ("tg_weight", C.c_float), ("composite", C.c_int), ("output_u8", C.c_int)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("lda", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int),
+                ("conv", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Cin", C.c_int),
+                ("stride", C.c_int), ("pad", C.c_int), ("upsample2x", C.c_int),
+                ("flags", C.c_int), ("tile", C.c_int), ("splits", C.c_int)]
+
+
+GF_BIAS, GF_BIAS_M, GF_RESID, GF_GEGLU, GF_GELU, GF_QUICKGELU, GF_OUT_F32 = 1, 2, 4, 8, 64, 128, 256
+
+# every symbol include/dtp.h declares: name -> (restype, argtypes)
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+SYMBOLS = {
+    "dtp_abi_version": (_i, []),
+    "dtp_last_error": (C.c_char_p, []),
+    "dtp_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
+    "dtp_destroy": (None, [_vp]),
+    "dtp_load_tensor": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(_i64), _i]),
+    "dtp_finalize_weights": (_i, [_vp]),
+    "dtp_vae_encode": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "dtp_unet": (_i, [_vp, _vp, _f, _vp, _vp, _i, _vp]),
+    "dtp_vae_decode": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "dtp_set_brush": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "dtp_set_conditioning": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "dtp_get_conditioning": (_i, [_vp, _vp, _vp, _vp]),
+    "dtp_stamp": (_i, [_vp, _vp, C.POINTER(Settings), _vp, _vp, _vp, _i, _vp]),
+    "dtp_last_stamp_times": (_i, [_vp, C.POINTER(_f * 3)]),
+    "dtp_last_stamp_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "dtp_op_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
+    "dtp_op_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "dtp_op_pack_conv": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "dtp_op_groupnorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "dtp_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
+    "dtp_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp]),
+    "dtp_op_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
+}
+
+
+def load():
+    """Load libdtp.so and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DtpError(f"{LIB_PATH} not found -- run `python -m diffusiontexturepainting_amd.build` "
+                       "(there is no CPU or PyTorch fallback for the stamp path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().dtp_last_error()
+        raise DtpError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

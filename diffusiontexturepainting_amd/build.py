@@ -1,0 +1,67 @@
+"""In-tree build of libdtp.so (hipcc, gfx950 only).  `python -m diffusiontexturepainting_amd.build`.
+
+The shared library lands next to the sources (diffusiontexturepainting_amd/libdtp.so): it is
+git-ignored but travels to the GPU box with the repo snapshot.
+"""
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libdtp.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stamp(path, extra=b""):
+    h = hashlib.sha1(extra)
+    for dep in [path] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + \
+            [os.path.join(os.path.dirname(HERE), "include", "dtp.h")]:
+        with open(dep, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _compile(src):
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ, src[:-4] + ".o")
+    tag = obj + ".sha1"
+    want = _stamp(path, " ".join(FLAGS).encode())
+    if os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == want:
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    with open(tag, "w") as f:
+        f.write(want)
+    return obj, True
+
+
+def build(verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+        results = list(ex.map(_compile, _sources()))
+    objs = [o for o, _ in results]
+    if any(changed for _, changed in results) or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[dtp.build] {LIB} ({os.path.getsize(LIB) // 1024} KiB) from {len(objs)} objects")
+    return LIB
+
+
+if __name__ == "__main__":
+    build()

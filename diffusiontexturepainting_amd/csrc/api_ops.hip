@@ -1,0 +1,148 @@
+// Kernel-level C-ABI entry points (include/dtp.h, "kernel-level entry points") and the error slot.
+#include <stdarg.h>
+#include <stdio.h>
+#include <mutex>
+#include <vector>
+
+#include "../../include/dtp.h"
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void dtp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+struct OpsScratch {
+  f16* zero = nullptr;
+  float* ws = nullptr;
+  size_t ws_bytes = 0;
+  int* geglu_map = nullptr;
+  int geglu_map_n = 0;
+  int num_cu = 256;
+  bool init = false;
+};
+OpsScratch g_ops;
+std::mutex g_ops_mu;
+
+int ops_init() {
+  if (g_ops.init) return DTP_OK;
+  HIP_CHECK(hipMalloc(&g_ops.zero, 256));
+  HIP_CHECK(hipMemset(g_ops.zero, 0, 256));
+  hipDeviceProp_t prop;
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+  g_ops.num_cu = prop.multiProcessorCount;
+  g_ops.init = true;
+  return DTP_OK;
+}
+
+int ops_ws(size_t bytes) {
+  if (bytes <= g_ops.ws_bytes) return DTP_OK;
+  HIP_CHECK(hipDeviceSynchronize());
+  if (g_ops.ws) HIP_CHECK(hipFree(g_ops.ws));
+  g_ops.ws = nullptr;
+  g_ops.ws_bytes = 0;
+  HIP_CHECK(hipMalloc(&g_ops.ws, bytes));
+  g_ops.ws_bytes = bytes;
+  return DTP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dtp_abi_version(void) { return DTP_ABI_VERSION; }
+const char* dtp_last_error(void) { return g_err; }
+
+int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s) {
+  std::lock_guard<std::mutex> lk(g_ops_mu);
+  int rc = ops_init();
+  if (rc) return rc;
+  GemmParams p = {};
+  p.A = (const f16*)d->A; p.W = (const f16*)d->W; p.C = d->C; p.bias = d->bias; p.R = (const f16*)d->R;
+  p.zero = g_ops.zero;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.lda = d->lda; p.ldw = d->ldw; p.ldc = d->ldc; p.ldr = d->ldr;
+  p.nkb = (d->K + 63) / 64;
+  p.Hi = d->Hi; p.Wi = d->Wi; p.Ho = d->Ho; p.Wo = d->Wo; p.Cin = d->Cin; p.stride = d->stride; p.pad = d->pad;
+  p.flags = d->flags | (d->conv ? GF_CONV3 : 0) | (d->upsample2x ? GF_UPS2 : 0);
+  if (p.ldw < p.nkb * 64) { dtp_set_error("gemm: ldw=%d smaller than padded K=%d", p.ldw, p.nkb * 64); return DTP_ERR_ARG; }
+  int tile = 0;
+  dtp_gemm_pick(p, &tile, g_ops.num_cu);
+  if (d->tile >= 0) tile = d->tile;
+  if (d->splits >= 1) {
+    p.kb_per_split = (p.nkb + d->splits - 1) / d->splits;
+    p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
+  }
+  rc = ops_ws(dtp_gemm_workspace_bytes(p));
+  if (rc) return rc;
+  p.part = g_ops.ws;
+  return dtp_launch_gemm(p, tile, (hipStream_t)s);
+}
+
+int dtp_op_pack_linear(const float* w, void* out, int N, int K, int ldw, int geglu, dtp_stream s) {
+  std::lock_guard<std::mutex> lk(g_ops_mu);
+  int rc = ops_init();
+  if (rc) return rc;
+  const int* map = nullptr;
+  if (geglu) {
+    if (N % 256) { dtp_set_error("pack_linear: GEGLU needs N %% 256 == 0"); return DTP_ERR_ARG; }
+    // source row f (a-part) / N/2+f (gate) -> tile t=f/64: rows [128t, 128t+64) = a, [128t+64, 128t+128) = gate
+    std::vector<int> h(N);
+    for (int f = 0; f < N / 2; ++f) {
+      h[f] = (f / 64) * 128 + (f % 64);
+      h[N / 2 + f] = (f / 64) * 128 + 64 + (f % 64);
+    }
+    if (g_ops.geglu_map_n < N) {
+      if (g_ops.geglu_map) HIP_CHECK(hipFree(g_ops.geglu_map));
+      HIP_CHECK(hipMalloc(&g_ops.geglu_map, sizeof(int) * N));
+      g_ops.geglu_map_n = N;
+    }
+    HIP_CHECK(hipMemcpyAsync(g_ops.geglu_map, h.data(), sizeof(int) * N, hipMemcpyHostToDevice, (hipStream_t)s));
+    HIP_CHECK(hipStreamSynchronize((hipStream_t)s));
+    map = g_ops.geglu_map;
+  }
+  return dtp_launch_pack_linear_weight(w, (f16*)out, N, K, ldw, map, (hipStream_t)s);
+}
+
+int dtp_op_pack_conv(const float* w, void* out, int Cout, int Cin, int Cin_pad, int taps, int ldw, dtp_stream s) {
+  return dtp_launch_pack_conv_weight(w, (f16*)out, Cout, Cin, Cin_pad, taps, ldw, (hipStream_t)s);
+}
+
+int dtp_op_groupnorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
+                     int groups, float eps, int silu, dtp_stream s) {
+  std::lock_guard<std::mutex> lk(g_ops_mu);
+  int rc = ops_init();
+  if (rc) return rc;
+  rc = ops_ws(dtp_groupnorm_ws_bytes(B, HW, C, groups));
+  if (rc) return rc;
+  return dtp_launch_groupnorm((const f16*)x, ldx, (f16*)y, ldy, gamma, beta, g_ops.ws, B, HW, C, groups, eps, silu,
+                              (hipStream_t)s);
+}
+
+int dtp_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int rows, int C,
+                     float eps, dtp_stream s) {
+  return dtp_launch_layernorm((const f16*)x, ldx, (f16*)y, ldy, gamma, beta, rows, C, eps, (hipStream_t)s);
+}
+
+int dtp_op_attention(const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo, int B, int H,
+                     int Sq, int Skv, int D, int64_t qbs, int64_t kbs, int64_t vbs, int64_t obs, float scale, dtp_stream s) {
+  AttnParams p;
+  p.Q = (const f16*)Q; p.K = (const f16*)K; p.V = (const f16*)V; p.O = (f16*)O;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.D = D;
+  p.qbs = qbs; p.kbs = kbs; p.vbs = vbs; p.obs = obs;
+  p.scale = scale;
+  return dtp_launch_attention(p, (hipStream_t)s);
+}
+
+int dtp_op_softmax_rows(const void* x, int ldx, void* y, int ldy, int rows, int cols, float scale, dtp_stream s) {
+  return dtp_launch_softmax_rows((const f16*)x, ldx, (f16*)y, ldy, rows, cols, scale, (hipStream_t)s);
+}
+
+}  // extern "C"

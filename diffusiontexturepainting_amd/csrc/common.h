@@ -1,0 +1,94 @@
+// Shared device/host declarations for the gfx950 (MI355X, CDNA4) kernels of libdtp.
+// Wave = 64 lanes everywhere in this code base; activations are NHWC fp16
+// ("tokens x channels", row stride `ld` in elements), accumulation is fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DTP_WAVE 64
+
+#define HIP_CHECK(x)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (x);                                                                    \
+    if (e_ != hipSuccess) {                                                                 \
+      dtp_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));       \
+      return DTP_ERR_HIP;                                                                   \
+    }                                                                                       \
+  } while (0)
+
+enum { DTP_OK = 0, DTP_ERR_ARG = 1, DTP_ERR_HIP = 2, DTP_ERR_STATE = 3, DTP_ERR_MISSING = 4 };
+
+void dtp_set_error(const char* fmt, ...);
+
+// ---------------------------------------------------------------- implicit GEMM (gemm_conv.hip)
+enum {
+  GF_BIAS = 1,       // += bias[n] (fp32)
+  GF_BIAS_M = 2,     // += bias[m] (fp32) -- operand-swapped calls (V^T = Wv X^T)
+  GF_RESID = 4,      // += R[m][n]
+  GF_GEGLU = 8,      // out[m][f] = a * gelu(g); W rows packed [a(BN/2) | g(BN/2)] per 128-col tile
+  GF_CONV3 = 16,     // A is an im2col view of an NHWC tensor (3x3 taps)
+  GF_UPS2 = 32,      // conv input is the nearest-2x upsample of A (fused gather)
+  GF_GELU = 64,      // out = gelu_erf(x)
+  GF_QUICKGELU = 128,// out = x * sigmoid(1.702 x)
+  GF_OUT_F32 = 256,  // C is fp32 (ldc in floats)
+};
+
+struct GemmParams {
+  const f16* A;      // activations: dense [M][lda] or NHWC image for CONV3
+  const f16* W;      // weights [N_pad][ldw], K contiguous, zero padded to k-block multiples
+  void* C;           // fp16 [M][ldc] (or fp32 with GF_OUT_F32)
+  float* part;       // split-K partial slabs [splits][M][N] fp32 (when splits > 1)
+  const float* bias; // fp32
+  const f16* R;      // residual [M][ldr]
+  const f16* zero;   // >= 16 bytes of zeros in device memory (source for padded taps)
+  int M, N, K;
+  int lda, ldw, ldc, ldr;
+  int nkb;           // number of 64-wide k-blocks in total
+  int splits;        // grid.z
+  int kb_per_split;
+  int Hi, Wi, Ho, Wo, Cin, stride, pad;  // CONV3 geometry (Hi/Wi are the stored input dims)
+  int flags;
+};
+
+// tile: 0 = 128x128, 1 = 128(M)x64(N), 2 = 64x64, 3 = 64(M)x128(N) ; -1 = heuristic
+int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s);
+int dtp_launch_splitk_reduce(const GemmParams& p, hipStream_t s);
+size_t dtp_gemm_workspace_bytes(const GemmParams& p);
+void dtp_gemm_pick(GemmParams& p, int* tile, int num_cu);  // sets splits/kb_per_split
+
+// ---------------------------------------------------------------- norms (norm.hip)
+// GroupNorm over NHWC [B][HW][C] (row stride ld), optional fused SiLU, fp32 statistics.
+int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, float* stats_ws,
+                         int B, int HW, int C, int groups, float eps, int silu, hipStream_t s);
+size_t dtp_groupnorm_ws_bytes(int B, int HW, int C, int groups);
+int dtp_launch_layernorm(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, int rows, int C,
+                         float eps, hipStream_t s);
+int dtp_launch_softmax_rows(const f16* x, int ldx, f16* y, int ldy, int rows, int cols, float scale, hipStream_t s);
+
+// ---------------------------------------------------------------- attention (attention.hip)
+struct AttnParams {
+  const f16 *Q, *K, *V;
+  f16* O;
+  int ldq, ldk, ldv, ldo;       // row strides (elements)
+  int B, H, Sq, Skv, D;         // head h reads columns [h*D, (h+1)*D)
+  long long qbs, kbs, vbs, obs; // batch strides (elements)
+  float scale;
+};
+int dtp_launch_attention(const AttnParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------- elementwise / layout (elementwise.hip)
+int dtp_launch_concat_channels(const f16* a, int lda, int Ca, const f16* b, int ldb, int Cb, f16* y, int ldy, long long rows,
+                               hipStream_t s);
+int dtp_launch_f32_to_f16(const float* x, f16* y, long long n, hipStream_t s);
+int dtp_launch_nchw_f32_to_nhwc_f16(const float* x, f16* y, int B, int C, int HW, int Cpad, hipStream_t s);
+int dtp_launch_nhwc_f16_to_nchw_f32(const f16* x, int ldx, float* y, int B, int C, int HW, hipStream_t s);
+int dtp_launch_pack_conv_weight(const float* w, f16* out, int Cout, int Cin, int Cin_pad, int taps, int ldw, hipStream_t s);
+int dtp_launch_pack_linear_weight(const float* w, f16* out, int N, int K, int ldw, const int* row_map, hipStream_t s);
+int dtp_launch_lora_merge(float* w, const float* up, const float* down, int N, int K, int rank, float scale, hipStream_t s);

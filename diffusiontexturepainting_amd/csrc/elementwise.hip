@@ -1,0 +1,122 @@
+// Layout / packing / elementwise kernels (HBM-bound; 16-byte accesses where the layout allows).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void concat_kernel(const f16* __restrict__ a, int lda, int Ca, const f16* __restrict__ b,
+                                                      int ldb, int Cb, f16* __restrict__ y, int ldy, long long rows) {
+  const int nca = Ca >> 3, nc = (Ca + Cb) >> 3;
+  const long long total = rows * nc;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / nc;
+    const int c = (int)(i - r * nc);
+    const f16x8 v = (c < nca) ? *(const f16x8*)(a + (size_t)r * lda + c * 8) : *(const f16x8*)(b + (size_t)r * ldb + (c - nca) * 8);
+    *(f16x8*)(y + (size_t)r * ldy + c * 8) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ x, f16* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = (f16)x[i];
+}
+
+// x [B][C][HW] f32 -> y [B][HW][Cpad] f16 (channels >= C zero filled)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, f16* __restrict__ y, int B, int C,
+                                                            int HW, int Cpad) {
+  const long long total = (long long)B * HW * Cpad;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % Cpad);
+    const long long pix = i / Cpad;
+    const int b = (int)(pix / HW), hw = (int)(pix - (long long)b * HW);
+    y[i] = (c < C) ? (f16)x[((size_t)b * C + c) * HW + hw] : (f16)0.f;
+  }
+}
+
+// x [B][HW][ldx] f16 -> y [B][C][HW] f32
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const f16* __restrict__ x, int ldx, float* __restrict__ y, int B,
+                                                            int C, int HW) {
+  const long long total = (long long)B * C * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int hw = (int)(i % HW);
+    const long long bc = i / HW;
+    const int c = (int)(bc % C), b = (int)(bc / C);
+    y[i] = (float)x[((size_t)b * HW + hw) * ldx + c];
+  }
+}
+
+// w [Cout][Cin][taps] f32 (PyTorch OIHW, taps = kh*kw) -> out [Cout][ldw] f16 with k = tap*Cin_pad + ci
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, f16* __restrict__ out, int Cout, int Cin,
+                                                         int Cin_pad, int taps, int ldw) {
+  const long long total = (long long)Cout * Cin * taps;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int t = (int)(i % taps);
+    const long long oc = i / taps;
+    const int ci = (int)(oc % Cin), co = (int)(oc / Cin);
+    out[(size_t)co * ldw + t * Cin_pad + ci] = (f16)w[i];
+  }
+}
+
+// w [N][K] f32 -> out[row_map ? row_map[n] : n][ldw] f16
+__global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restrict__ w, f16* __restrict__ out, int N, int K,
+                                                           int ldw, const int* __restrict__ row_map) {
+  const long long total = (long long)N * K;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % K), n = (int)(i / K);
+    const int r = row_map ? row_map[n] : n;
+    out[(size_t)r * ldw + k] = (f16)w[i];
+  }
+}
+
+// W[n][k] += scale * sum_r up[n][r] * down[r][k]   (trt_inference/models.py:1083)
+__global__ __launch_bounds__(256) void lora_merge_kernel(float* __restrict__ w, const float* __restrict__ up,
+                                                          const float* __restrict__ down, int N, int K, int rank, float scale) {
+  const long long total = (long long)N * K;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % K), n = (int)(i / K);
+    float acc = 0.f;
+    for (int r = 0; r < rank; ++r) acc += up[(size_t)n * rank + r] * down[(size_t)r * K + k];
+    w[i] += scale * acc;
+  }
+}
+
+inline int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+#define LAUNCH_RET() return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP
+
+int dtp_launch_concat_channels(const f16* a, int lda, int Ca, const f16* b, int ldb, int Cb, f16* y, int ldy, long long rows,
+                               hipStream_t s) {
+  if ((Ca | Cb | lda | ldb | ldy) & 7) { dtp_set_error("concat: channel counts / strides must be multiples of 8"); return DTP_ERR_ARG; }
+  hipLaunchKernelGGL(concat_kernel, dim3(grid_for(rows * ((Ca + Cb) / 8))), dim3(256), 0, s, a, lda, Ca, b, ldb, Cb, y, ldy, rows);
+  LAUNCH_RET();
+}
+int dtp_launch_f32_to_f16(const float* x, f16* y, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
+  LAUNCH_RET();
+}
+int dtp_launch_nchw_f32_to_nhwc_f16(const float* x, f16* y, int B, int C, int HW, int Cpad, hipStream_t s) {
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)B * HW * Cpad)), dim3(256), 0, s, x, y, B, C, HW, Cpad);
+  LAUNCH_RET();
+}
+int dtp_launch_nhwc_f16_to_nchw_f32(const f16* x, int ldx, float* y, int B, int C, int HW, hipStream_t s) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long long)B * C * HW)), dim3(256), 0, s, x, ldx, y, B, C, HW);
+  LAUNCH_RET();
+}
+int dtp_launch_pack_conv_weight(const float* w, f16* out, int Cout, int Cin, int Cin_pad, int taps, int ldw, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(grid_for((long long)Cout * Cin * taps)), dim3(256), 0, s, w, out, Cout, Cin,
+                     Cin_pad, taps, ldw);
+  LAUNCH_RET();
+}
+int dtp_launch_pack_linear_weight(const float* w, f16* out, int N, int K, int ldw, const int* row_map, hipStream_t s) {
+  hipLaunchKernelGGL(pack_linear_kernel, dim3(grid_for((long long)N * K)), dim3(256), 0, s, w, out, N, K, ldw, row_map);
+  LAUNCH_RET();
+}
+int dtp_launch_lora_merge(float* w, const float* up, const float* down, int N, int K, int rank, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(lora_merge_kernel, dim3(grid_for((long long)N * K)), dim3(256), 0, s, w, up, down, N, K, rank, scale);
+  LAUNCH_RET();
+}

@@ -1,0 +1,369 @@
+// Implicit-GEMM kernel for gfx950: C[m][n] = epilogue( sum_k A(m,k) * W[n][k] ).
+//
+// One kernel serves every dense contraction on the stamp path:
+//   * Linear / 1x1 conv:  A(m,k) = a[m*lda + k]
+//   * 3x3 conv (stride 1/2, optional fused nearest-2x upsample of the input):
+//     A is an im2col VIEW of the NHWC activation, gathered straight into LDS; padded taps
+//     read a 16-byte zero page, so no im2col buffer ever exists in HBM.
+//
+// CDNA4 mapping: 256 threads = 4 waves (2 along N x 2 along M), v_mfma_f32_32x32x16_f16,
+// fp32 accumulators.  Both operands are staged K-contiguous in LDS by direct-to-LDS DMA
+// (global_load_lds_dwordx4, 1 KiB per wave-instruction, double buffered, one barrier per
+// 64-wide k-block).  LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with
+// (row>>1)&7 ON THE SOURCE ADDRESS (the DMA destination must stay lane-linear) and on the
+// ds_read_b128 side, which makes the 16-lane read groups bank-conflict free.  The weight
+// fragment is the MFMA A operand and the activation fragment the B operand, so a lane ends
+// up holding 4 consecutive output channels of one token -> 8-byte LDS writes into a staging
+// tile and fully coalesced 16-byte global stores with bias / residual / GEGLU fused.
+// Workgroup ids are remapped so each XCD (private L2) owns a contiguous range of tiles.
+#include "common.h"
+
+#define GF_MFAST 512  // internal: tile_m varies fastest (blocks adjacent in id share the W panel)
+
+namespace {
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA blocks per wave along M / N
+  constexpr int AR = BM / 32, WR = BN / 32;  // DMA wave-instructions per wave per k-block
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int SLD = BN + 8;                // staging-tile row stride (f16)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- XCD-aware tile assignment (bijective remap; block b runs on XCD b % 8)
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  int wg;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tile_m, tile_n;
+  if (p.flags & GF_MFAST) { tile_n = wg / tiles_m; tile_m = wg - tile_n * tiles_m; }
+  else { tile_m = wg / tiles_n; tile_n = wg - tile_m * tiles_n; }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kb0 = blockIdx.z * p.kb_per_split;
+  const int nk = min(p.kb_per_split, p.nkb - kb0);
+
+  // ---- DMA source state.  Row r = i*32 + wave*8 + (lane>>3); LDS slot = lane&7 holds source
+  // chunk slot ^ ((r>>1)&7).
+  const int lrow = wave * 8 + (lane >> 3);
+  const int kc = (((lane & 7) ^ ((lrow >> 1) & 7)) << 3);  // element offset inside the k-block
+  const bool conv = (p.flags & GF_CONV3) != 0;
+  const int ups = (p.flags & GF_UPS2) ? 1 : 0;
+  const int Hlim = p.Hi << ups, Wlim = p.Wi << ups;
+
+  const f16* a_row[AR];  // dense: row pointer (or zero page)
+  int a_pix[AR], a_y[AR], a_x[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = m0 + i * 32 + lrow;
+    if (conv) {
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw, rem = m - b * hw;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_pix[i] = b * p.Hi * p.Wi;
+      a_y[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 20);
+      a_x[i] = ox * p.stride - p.pad;
+      a_row[i] = nullptr;
+    } else {
+      a_row[i] = (m < p.M) ? p.A + (size_t)m * p.lda + kc : nullptr;
+      a_pix[i] = a_y[i] = a_x[i] = 0;
+    }
+  }
+  const f16* w_row[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) w_row[i] = p.W + (size_t)(n0 + i * 32 + lrow) * p.ldw + kc;
+
+  int tap = 0, cch = 0;  // conv: current tap and channel offset of this thread's chunk
+  if (conv) {
+    const int k = kb0 * 64 + kc;
+    tap = k / p.Cin;
+    cch = k - tap * p.Cin;
+  }
+
+  auto issue = [&](int stage, int kb) {
+    char* As = smem + stage * STAGE;
+    char* Ws = As + BM * 128;
+    if (conv) {
+      const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+        const bool ok = (tap < 9) && ((unsigned)iy < (unsigned)Hlim) && ((unsigned)ix < (unsigned)Wlim);
+        const f16* src = ok ? p.A + ((size_t)(a_pix[i] + (iy >> ups) * p.Wi + (ix >> ups)) * p.lda + cch) : p.zero;
+        glds16(src, As + (i * 32 + wave * 8) * 128);
+      }
+      cch += 64;
+      while (cch >= p.Cin) { cch -= p.Cin; ++tap; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const f16* src = a_row[i] ? a_row[i] + (size_t)kb * 64 : p.zero;
+        glds16(src, As + (i * 32 + wave * 8) * 128);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WR; ++i) glds16(w_row[i] + (size_t)kb * 64, Ws + (i * 32 + wave * 8) * 128);
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wn0 = (wave & 1) * (BN / 2), wm0 = (wave >> 1) * (BM / 2);
+  const int frow = lane & 31, fhalf = lane >> 5;
+
+  if (nk > 0) issue(0, kb0);
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // stage t&1 landed for every wave; everyone is done reading stage (t+1)&1
+    if (t + 1 < nk) issue((t + 1) & 1, kb0 + t + 1);
+    const char* As = smem + (t & 1) * STAGE;
+    const char* Ws = As + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks * 2 + fhalf;
+      f16x8 af[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int row = wm0 + j * 32 + frow;
+        af[j] = *(const f16x8*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int row = wn0 + i * 32 + frow;
+        wf[i] = *(const f16x8*)(Ws + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // D layout (32x32): lane holds column (lane&31) = token, rows (r&3)+8*(r>>2)+4*(lane>>5) = channel.
+  if (p.splits > 1) {
+    float* part = p.part + (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm0 + j * 32 + frow;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn0 + i * 32 + 8 * q + 4 * fhalf;
+          if (m < p.M) {
+            float* dst = part + (size_t)m * p.N + n;
+            if (n + 4 <= p.N && (p.N & 3) == 0) {
+              f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+              *(f32x4*)dst = v;
+            } else {
+              for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) dst[e] = acc[i][j][4 * q + e];
+            }
+          }
+        }
+      }
+    return;
+  }
+
+  __syncthreads();  // all waves finished reading the last stage before it is reused as staging
+  f16* stg = (f16*)smem;
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int ml = wm0 + j * 32 + frow;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nl = wn0 + i * 32 + 8 * q + 4 * fhalf;
+        f16x4 v = {(f16)acc[i][j][4 * q], (f16)acc[i][j][4 * q + 1], (f16)acc[i][j][4 * q + 2], (f16)acc[i][j][4 * q + 3]};
+        *(f16x4*)(stg + ml * SLD + nl) = v;
+      }
+    }
+  __syncthreads();
+
+  const int fl = p.flags;
+  if (fl & GF_GEGLU) {
+    // tile columns [0,BN/2) = a, [BN/2,BN) = gate of output features tile_n*BN/2 + ...
+    constexpr int HC = BN / 16;  // 8-wide chunks per half
+    f16* C = (f16*)p.C;
+    for (int idx = tid; idx < BM * HC; idx += 256) {
+      const int ml = idx / HC, nc = idx - ml * HC;
+      const int m = m0 + ml;
+      if (m >= p.M) continue;
+      const f16x8 a = *(const f16x8*)(stg + ml * SLD + nc * 8);
+      const f16x8 g = *(const f16x8*)(stg + ml * SLD + BN / 2 + nc * 8);
+      const float* ba = p.bias + n0 + nc * 8;
+      const float* bg = ba + BN / 2;
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float av = (float)a[e], gv = (float)g[e];
+        if (fl & GF_BIAS) { av += ba[e]; gv += bg[e]; }
+        o[e] = (f16)(av * gelu_erf(gv));
+      }
+      *(f16x8*)(C + (size_t)m * p.ldc + tile_n * (BN / 2) + nc * 8) = o;
+    }
+    return;
+  }
+
+  constexpr int NC = BN / 8;
+  const bool vec_ok = ((p.ldc & 7) == 0) && !(fl & GF_OUT_F32) && (!(fl & GF_RESID) || (p.ldr & 7) == 0);
+  for (int idx = tid; idx < BM * NC; idx += 256) {
+    const int ml = idx / NC, nc = idx - ml * NC;
+    const int m = m0 + ml, n = n0 + nc * 8;
+    if (m >= p.M || n >= p.N) continue;
+    const f16x8 v = *(const f16x8*)(stg + ml * SLD + nc * 8);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
+    const bool full = (n + 8 <= p.N);
+    if (fl & GF_BIAS) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (full || n + e < p.N) x[e] += p.bias[n + e];
+    }
+    if (fl & GF_BIAS_M) {
+      const float bm = p.bias[m];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += bm;
+    }
+    if (fl & GF_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = gelu_erf(x[e]);
+    }
+    if (fl & GF_QUICKGELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = x[e] / (1.0f + __expf(-1.702f * x[e]));
+    }
+    if (full && vec_ok) {
+      if (fl & GF_RESID) {
+        const f16x8 r = *(const f16x8*)(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += (float)r[e];
+      }
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (f16)x[e];
+      *(f16x8*)((f16*)p.C + (size_t)m * p.ldc + n) = o;
+    } else {
+      for (int e = 0; e < 8; ++e) {
+        if (n + e >= p.N) break;
+        float y = x[e];
+        if (fl & GF_RESID) y += (float)p.R[(size_t)m * p.ldr + n + e];
+        if (fl & GF_OUT_F32) ((float*)p.C)[(size_t)m * p.ldc + n + e] = y;
+        else ((f16*)p.C)[(size_t)m * p.ldc + n + e] = (f16)y;
+      }
+    }
+  }
+}
+
+// Sum split-K slabs and apply the same (non-GEGLU) epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+  const long long total = (long long)p.M * p.N;
+  const int fl = p.flags;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / p.N), n = (int)(i - (long long)m * p.N);
+    float x = 0.f;
+    for (int z = 0; z < p.splits; ++z) x += p.part[(size_t)z * total + i];
+    if (fl & GF_BIAS) x += p.bias[n];
+    if (fl & GF_BIAS_M) x += p.bias[m];
+    if (fl & GF_GELU) x = gelu_erf(x);
+    if (fl & GF_QUICKGELU) x = x / (1.0f + __expf(-1.702f * x));
+    if (fl & GF_RESID) x += (float)p.R[(size_t)m * p.ldr + n];
+    if (fl & GF_OUT_F32) ((float*)p.C)[(size_t)m * p.ldc + n] = x;
+    else ((f16*)p.C)[(size_t)m * p.ldc + n] = (f16)x;
+  }
+}
+
+template <int BM, int BN>
+int launch_tile(const GemmParams& p, hipStream_t s) {
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  constexpr int lds = 2 * (BM + BN) * 128;
+  static_assert(lds >= BM * (BN + 8) * 2, "staging tile must fit in the pipeline buffers");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<BM, BN>), dim3(tiles, 1, p.splits), dim3(256), lds, s, p);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
+
+}  // namespace
+
+size_t dtp_gemm_workspace_bytes(const GemmParams& p) {
+  return p.splits > 1 ? (size_t)p.splits * p.M * p.N * sizeof(float) : 0;
+}
+
+void dtp_gemm_pick(GemmParams& p, int* tile, int num_cu) {
+  const bool geglu = (p.flags & GF_GEGLU) != 0;
+  int t;
+  const bool n128 = (p.N % 128) == 0;
+  if (p.M >= 512) t = (n128 || p.N < 64 ? 0 : 1);
+  else t = (n128 ? 3 : 2);
+  if (p.N <= 64 && p.M >= 512) t = 1;
+  if (geglu) t = (p.M >= 512) ? 0 : 3;
+  static const int bm[4] = {128, 128, 64, 64}, bn[4] = {128, 64, 64, 128};
+  const long long blocks = (long long)((p.M + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]);
+  int splits = 1;
+  if (!geglu && blocks * 2 <= num_cu && p.nkb >= 8) {
+    splits = (int)((2LL * num_cu + blocks - 1) / blocks);
+    if (splits > p.nkb / 4) splits = p.nkb / 4;
+    if (splits > 32) splits = 32;
+    if (splits < 1) splits = 1;
+  }
+  p.kb_per_split = (p.nkb + splits - 1) / splits;
+  p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
+  // share the bigger operand panel between neighbouring workgroups
+  const double a_bytes = (double)p.M * (double)(p.flags & GF_CONV3 ? p.Cin : p.K);
+  const double w_bytes = (double)p.N * (double)p.K;
+  if (w_bytes > a_bytes) p.flags |= GF_MFAST; else p.flags &= ~GF_MFAST;
+  *tile = t;
+}
+
+int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
+  if (p.nkb <= 0 || p.M <= 0 || p.N <= 0) { dtp_set_error("gemm: empty problem"); return DTP_ERR_ARG; }
+  if ((p.lda & 7) || (p.ldw & 7)) { dtp_set_error("gemm: lda/ldw must be multiples of 8"); return DTP_ERR_ARG; }
+  if ((p.flags & GF_CONV3) && (p.Cin & 7)) { dtp_set_error("conv: Cin must be a multiple of 8"); return DTP_ERR_ARG; }
+  if ((p.flags & GF_GEGLU) && (p.splits > 1 || !(tile == 0 || tile == 3) || (p.N % 128))) {
+    dtp_set_error("gemm: GEGLU needs a 128-wide N tile, N %% 128 == 0 and no split-K");
+    return DTP_ERR_ARG;
+  }
+  int rc;
+  switch (tile) {
+    case 0: rc = launch_tile<128, 128>(p, s); break;
+    case 1: rc = launch_tile<128, 64>(p, s); break;
+    case 2: rc = launch_tile<64, 64>(p, s); break;
+    case 3: rc = launch_tile<64, 128>(p, s); break;
+    default: dtp_set_error("gemm: bad tile id %d", tile); return DTP_ERR_ARG;
+  }
+  if (rc != DTP_OK) { dtp_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
+  if (p.splits > 1) return dtp_launch_splitk_reduce(p, s);
+  return DTP_OK;
+}
+
+int dtp_launch_splitk_reduce(const GemmParams& p, hipStream_t s) {
+  long long total = (long long)p.M * p.N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}

@@ -1,0 +1,124 @@
+"""Thin torch-tensor wrappers over the kernel-level C-ABI entry points (dtp_op_*).
+
+torch is only the owner of device memory here: every function hands raw pointers to
+libdtp.so and returns the output tensor.  Activations are NHWC fp16.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GF_BIAS, GF_BIAS_M, GF_GEGLU, GF_GELU, GF_OUT_F32, GF_QUICKGELU, GF_RESID, GemmDesc, check, ptr
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _up(x, m):
+    return (x + m - 1) // m * m
+
+
+def pack_linear(w, geglu=False):
+    """w f32 [N,K] (device) -> f16 [roundup(N,128), roundup(K,64)] in the kernel layout."""
+    lib = _lib.load()
+    n, k = w.shape
+    out = torch.zeros(_up(n, 128), _up(k, 64), dtype=torch.float16, device=w.device)
+    w = w.contiguous().float()
+    check(lib.dtp_op_pack_linear(ptr(w), ptr(out), n, k, out.shape[1], int(geglu), _stream()), "pack_linear")
+    return out
+
+
+def pack_conv(w, cin_pad=None):
+    """w f32 [Cout,Cin,kh,kw] -> f16 [roundup(Cout,128), roundup(taps*cin_pad,64)], k = tap*cin_pad + ci."""
+    lib = _lib.load()
+    cout, cin, kh, kw = w.shape
+    cin_pad = cin_pad or _up(cin, 8)
+    out = torch.zeros(_up(cout, 128), _up(kh * kw * cin_pad, 64), dtype=torch.float16, device=w.device)
+    w = w.contiguous().float()
+    check(lib.dtp_op_pack_conv(ptr(w), ptr(out), cout, cin, cin_pad, kh * kw, out.shape[1], _stream()), "pack_conv")
+    return out
+
+
+def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, out=None, lda=None):
+    """a f16 [M, >=K] row-major; wp packed weights; returns f16 [M, N] (or [M, N/2] with GEGLU)."""
+    lib = _lib.load()
+    m = a.shape[0]
+    k = k or a.shape[1]
+    n_out = n // 2 if flags & GF_GEGLU else n
+    if out is None:
+        out = torch.empty(m, n_out, dtype=torch.float32 if flags & GF_OUT_F32 else torch.float16, device=a.device)
+    d = GemmDesc()
+    d.A, d.W, d.C = a.data_ptr(), wp.data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.R = resid.data_ptr() if resid is not None else None
+    d.M, d.N, d.K = m, n, k
+    d.lda, d.ldw, d.ldc = lda or a.stride(0), wp.stride(0), out.stride(0)
+    d.ldr = resid.stride(0) if resid is not None else 0
+    d.flags = flags | (GF_BIAS if bias is not None and not flags & GF_BIAS_M else 0) | (GF_RESID if resid is not None else 0)
+    d.tile, d.splits = tile, splits
+    check(lib.dtp_op_gemm(C.byref(d), _stream()), "gemm")
+    return out
+
+
+def conv3x3(x, wp, cout, stride=1, pad=1, upsample=False, bias=None, resid=None, tile=-1, splits=0, out_hw=None, flags=0):
+    """x f16 NHWC [B,H,W,C] -> f16 NHWC [B,Ho,Wo,cout].  pad is the top/left zero padding; bottom/right
+    padding is implied by out_hw (default: the symmetric-padding output size)."""
+    lib = _lib.load()
+    b, h, w, cin = x.shape
+    hv, wv = (2 * h, 2 * w) if upsample else (h, w)
+    ho, wo = out_hw or ((hv + 2 * pad - 3) // stride + 1, (wv + 2 * pad - 3) // stride + 1)
+    out = torch.empty(b, ho, wo, cout, dtype=torch.float32 if flags & GF_OUT_F32 else torch.float16, device=x.device)
+    d = GemmDesc()
+    d.A, d.W, d.C = x.data_ptr(), wp.data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.R = resid.data_ptr() if resid is not None else None
+    d.M, d.N, d.K = b * ho * wo, cout, 9 * cin
+    d.lda, d.ldw, d.ldc = x.stride(2), wp.stride(0), cout
+    d.ldr = resid.stride(2) if resid is not None else 0
+    d.conv, d.Hi, d.Wi, d.Ho, d.Wo, d.Cin, d.stride, d.pad, d.upsample2x = 1, h, w, ho, wo, cin, stride, pad, int(upsample)
+    d.flags = flags | (GF_BIAS if bias is not None else 0) | (GF_RESID if resid is not None else 0)
+    d.tile, d.splits = tile, splits
+    check(lib.dtp_op_gemm(C.byref(d), _stream()), "conv3x3")
+    return out
+
+
+def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False):
+    """x f16 NHWC [B,H,W,C] (or [B,HW,C])."""
+    lib = _lib.load()
+    b, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (b * c)
+    y = torch.empty_like(x)
+    check(lib.dtp_op_groupnorm(ptr(x), c, ptr(y), c, ptr(gamma), ptr(beta), b, hw, c, groups, eps, int(silu), _stream()),
+          "groupnorm")
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    lib = _lib.load()
+    c = x.shape[-1]
+    rows = x.numel() // c
+    y = torch.empty_like(x)
+    check(lib.dtp_op_layernorm(ptr(x), c, ptr(y), c, ptr(gamma), ptr(beta), rows, c, eps, _stream()), "layernorm")
+    return y
+
+
+def attention(q, k, v, heads, scale=None):
+    """q [B,Sq,C], k/v [B,Skv,C] f16 (last dim contiguous; may be column slices of a fused buffer)."""
+    lib = _lib.load()
+    b, sq, c = q.shape
+    skv = k.shape[1]
+    d = c // heads
+    o = torch.empty(b, sq, c, dtype=torch.float16, device=q.device)
+    scale = scale if scale is not None else d ** -0.5
+    check(lib.dtp_op_attention(ptr(q), ptr(k), ptr(v), ptr(o), q.stride(1), k.stride(1), v.stride(1), o.stride(1), b, heads,
+                               sq, skv, d, q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, _stream()), "attention")
+    return o
+
+
+def softmax_rows(x, scale=1.0):
+    lib = _lib.load()
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    check(lib.dtp_op_softmax_rows(ptr(x), x.stride(0), ptr(y), y.stride(0), rows, cols, scale, _stream()), "softmax_rows")
+    return y

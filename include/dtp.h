@@ -1,0 +1,135 @@
+/* libdtp -- C ABI of the MI355X-native stamp-inpainting engine.
+ *
+ * Drop-in boundary for the hot path of nv-tlabs/DiffusionTexturePainting's trt_inference/
+ * server.  Plain C: opaque handle, raw device pointers, sizes and int
+ * error codes; no exceptions and no torch/TensorRT types cross this line.  One handle = one
+ * GPU + one stream at a time; a handle is NOT thread-safe (the reference is single-threaded:
+ * one tornado IOLoop, one stamp in flight -- trt_inference/handler.py:78-110).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to
+ * trt_inference/).  Tensors are dense, row-major, in the reference's own layouts (NCHW fp32
+ * images / latents, [N,14,768] conditioning); the NHWC fp16 working layout is internal.
+ * Every function returns DTP_OK (0) or an error code; dtp_last_error() gives the message.
+ */
+#ifndef DTP_H
+#define DTP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTP_ABI_VERSION 1
+
+enum { DTP_SUCCESS = 0, DTP_E_ARG = 1, DTP_E_HIP = 2, DTP_E_STATE = 3, DTP_E_MISSING = 4 };
+
+typedef struct dtp_ctx dtp_ctx;
+typedef void* dtp_stream; /* hipStream_t; NULL = the null stream */
+
+int dtp_abi_version(void);
+const char* dtp_last_error(void);
+
+/* ---------------------------------------------------------------- lifecycle
+ * replaces: TRTConditionalInpainter.__init__ (trt_model.py:28-71) -> InpaintPipeline(...)
+ * + loadEngines + loadResources (stable_diffusion_pipeline.py:138-162,189-334).
+ * `resolution` is fixed per handle like the reference's (run.py:30); max_batch = stamps per call. */
+int dtp_create(int device, int resolution, int max_batch, dtp_ctx** out);
+void dtp_destroy(dtp_ctx* ctx);
+
+/* ---------------------------------------------------------------- weights
+ * replaces: UNet2DConditionModel / AutoencoderKL.from_pretrained + load_attn_procs
+ * (models.py:1038-1042,1241,1332), torch.load(image_encoder.pth) (trt_model.py:57-59).
+ * `name` is "<net>.<diffusers key>" with net in {unet, lora, vae, clip, penc}; data is fp32,
+ * host or device memory.  dtp_finalize_weights merges LoRA (W += up @ down, models.py:1083),
+ * packs everything to the fp16 kernel layouts and builds the launch programs. */
+int dtp_load_tensor(dtp_ctx* ctx, const char* name, const float* data, int is_device, const int64_t* shape, int ndim);
+int dtp_finalize_weights(dtp_ctx* ctx);
+
+/* ---------------------------------------------------------------- engines (inner boundary)
+ * replaces: Engine.infer(feed_dict, stream) for the three TensorRT engines (utilities.py:252-264,
+ * runEngine stable_diffusion_pipeline.py:336-338) with the I/O contracts of models.py:1343-1377
+ * (vae_encoder), :1097-1139 (unet), :1253-1284 (vae).  Pointers are device memory.
+ *   vae_encoder: images f32 [B,3,R,R] -> latent f32 [B,4,h,w] = mean + exp(.5 logvar) * eps
+ *                (eps f32 [B,4,h,w]; NULL = distribution mean).  Unscaled, like the engine.
+ *   unet:        sample f32 [N,9,h,w], timestep f32 scalar, encoder_hidden_states f16 [N,14,768]
+ *                -> f32 [N,4,h,w]
+ *   vae:         latent f32 [B,4,h,w] -> images f32 [B,3,R,R] */
+int dtp_vae_encode(dtp_ctx* ctx, const float* images, const float* eps, float* latent, int B, dtp_stream s);
+int dtp_unet(dtp_ctx* ctx, const float* sample, float timestep, const void* ctx_f16, float* out, int N, dtp_stream s);
+int dtp_vae_decode(dtp_ctx* ctx, const float* latent, float* images, int B, dtp_stream s);
+
+/* ---------------------------------------------------------------- operator (primary boundary)
+ * dtp_set_brush replaces TRTConditionalInpainter.set_brush (trt_model.py:79-88):
+ *   crop_resize_square (handler.py:36-45) + ConditionPatchEncoder.encode_image
+ *   (image_encoder.py:106-115).  image f32 [3,H,W] 0..1 (device); writes the resized brush
+ *   f32 [1,3,R,R] to image_out (the `.image` attribute handler.py:97 reads).
+ * dtp_set_conditioning installs precomputed conditioning instead (cond/uncond f32 [14,768],
+ *   brush f32 [3,R,R]; device pointers). */
+int dtp_set_brush(dtp_ctx* ctx, const float* image, int H, int W, float* image_out, dtp_stream s);
+int dtp_set_conditioning(dtp_ctx* ctx, const float* cond, const float* uncond, const float* brush, dtp_stream s);
+int dtp_get_conditioning(dtp_ctx* ctx, float* cond, float* uncond, dtp_stream s);
+
+typedef struct {
+  int steps;        /* settings['steps']        (server_io.py:104) */
+  int context_pad;  /* settings['context_pad']  */
+  int tg_steps;     /* settings['tg_steps']     */
+  float cfg_weight; /* settings['cfg_weight']   */
+  float tg_weight;  /* settings['tg_weight']    */
+  int composite;    /* 0 = generate_raw (trt_model.py:90-121); 1 = generate (model_base.py:51-58) */
+  int output_u8;    /* 1: out is u8 HWC [B,R,R,3] = (img*255) truncated (handler.py:55-56) */
+} dtp_settings;
+
+/* replaces TRTConditionalInpainter.generate_raw / ConditionalInpainterBase.generate.
+ *   canvas  f32 [B,4,R,R] 0..1, alpha 1 = known
+ *   latents f32 [B,4,h,w]   initial N(0,1) draw (initialize_latents, sdp:340-346); required
+ *   vae_eps f32 [2,B,4,h,w] normal draws of the two VAE encodes (models.py:1335); NULL = mean
+ *   out     f32 [B,3,R,R] 0..1 (or u8, see output_u8)
+ * Asynchronous on `s`. */
+int dtp_stamp(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const float* latents, const float* vae_eps,
+              void* out, int B, dtp_stream s);
+
+/* per-stage GPU time of the last dtp_stamp on this handle, ms (print_summary,
+ * stable_diffusion_pipeline.py:486-503): [0]=pre+vae_encoder x2, [1]=denoise loop, [2]=vae decode+post.
+ * Blocks until the stamp has finished. */
+int dtp_last_stamp_times(dtp_ctx* ctx, float ms[3]);
+/* number of UNet evaluations / kernel launches captured for the last stamp */
+int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes);
+
+/* ---------------------------------------------------------------- kernel-level entry points
+ * The individual HIP kernels behind the engines, exposed so each can
+ * be parity-tested and profiled on its own.  All pointers are device memory; fp16 activations
+ * are NHWC ("tokens x channels", row stride ld in elements). */
+typedef struct {
+  const void* A;     /* f16 activations: [M][lda], or NHWC image when conv=1 */
+  const void* W;     /* f16 packed weights [>=roundup(N,128)][ldw] (dtp_op_pack_*) */
+  void* C;           /* f16 [M][ldc] (f32 when flags & DTP_GF_OUT_F32) */
+  const float* bias; /* f32 or NULL */
+  const void* R;     /* f16 residual [M][ldr] or NULL */
+  int M, N, K;       /* conv: K = 9*Cin */
+  int lda, ldw, ldc, ldr;
+  int conv, Hi, Wi, Ho, Wo, Cin, stride, pad, upsample2x;
+  int flags;         /* DTP_GF_* */
+  int tile;          /* -1 = heuristic; 0:128x128 1:128x64 2:64x64 3:64x128 (MxN) */
+  int splits;        /* 0 = heuristic; >=1 = forced split-K factor */
+} dtp_gemm_desc;
+enum { DTP_GF_BIAS = 1, DTP_GF_BIAS_M = 2, DTP_GF_RESID = 4, DTP_GF_GEGLU = 8, DTP_GF_GELU = 64, DTP_GF_QUICKGELU = 128,
+       DTP_GF_OUT_F32 = 256 };
+
+int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s);
+/* w f32 [N][K] -> out f16 [rows][ldw] (caller zero-fills out); geglu=1 applies the [a|gate] tile packing */
+int dtp_op_pack_linear(const float* w, void* out, int N, int K, int ldw, int geglu, dtp_stream s);
+/* w f32 [Cout][Cin][3][3] (or 1x1) -> out f16 [rows][ldw], k = tap*Cin_pad + ci (caller zero-fills out) */
+int dtp_op_pack_conv(const float* w, void* out, int Cout, int Cin, int Cin_pad, int taps, int ldw, dtp_stream s);
+int dtp_op_groupnorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
+                     int groups, float eps, int silu, dtp_stream s);
+int dtp_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int rows, int C,
+                     float eps, dtp_stream s);
+int dtp_op_attention(const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo, int B, int H,
+                     int Sq, int Skv, int D, int64_t qbs, int64_t kbs, int64_t vbs, int64_t obs, float scale, dtp_stream s);
+int dtp_op_softmax_rows(const void* x, int ldx, void* y, int ldy, int rows, int cols, float scale, dtp_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTP_H */
