@@ -44,6 +44,7 @@ SYMBOLS = {
     "dtp_set_conditioning": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "dtp_get_conditioning": (_i, [_vp, _vp, _vp, _vp]),
     "dtp_stamp": (_i, [_vp, _vp, C.POINTER(Settings), _vp, _vp, _vp, _i, _vp]),
+    "dtp_ddim_tables": (_i, [_i, C.POINTER(_i64), C.POINTER(_f), C.POINTER(_f)]),
     "dtp_last_stamp_times": (_i, [_vp, C.POINTER(_f * 3)]),
     "dtp_last_stamp_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "dtp_op_gemm": (_i, [C.POINTER(GemmDesc), _vp]),

@@ -38,6 +38,8 @@ enum {
   GF_GELU = 64,      // out = gelu_erf(x)
   GF_QUICKGELU = 128,// out = x * sigmoid(1.702 x)
   GF_OUT_F32 = 256,  // C is fp32 (ldc in floats)
+  GF_SILU = 512,     // out = x * sigmoid(x)
+  GF_MFAST = 1 << 20,// internal: tile_m varies fastest (neighbouring workgroups share the W panel)
 };
 
 struct GemmParams {

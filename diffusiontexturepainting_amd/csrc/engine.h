@@ -1,0 +1,233 @@
+// Host-side engine of libdtp: weight staging/packing, static activation planning and the
+// launch programs of the three networks.  One Ctx = one GPU; not thread-safe (include/dtp.h).
+#pragma once
+#include <functional>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/dtp.h"
+#include "common.h"
+
+#define RC(x)            \
+  do {                   \
+    int rc_ = (x);       \
+    if (rc_) return rc_; \
+  } while (0)
+
+struct Staged {
+  float* d = nullptr;  // device fp32
+  std::vector<int64_t> shape;
+  size_t n = 0;
+};
+
+struct ConvW {  // 3x3 (taps = 9) or 1x1 (taps = 1) convolution / any Linear (taps = 1)
+  f16* w = nullptr;
+  float* b = nullptr;  // fp32 bias (may be null)
+  int cout = 0, cin = 0 /* padded */, taps = 1, K = 0, ldw = 0;
+};
+struct NormW {
+  float *g = nullptr, *b = nullptr;
+  int c = 0;
+};
+
+// NHWC fp16 view
+struct T {
+  f16* p = nullptr;
+  int B = 0, H = 0, W = 0, C = 0, ld = 0;
+  long long rows() const { return (long long)B * H * W; }
+};
+
+struct Ctx;
+
+// A launch program: a flat list of closures bound to statically planned buffers.
+using Op = std::function<int(hipStream_t, int /*step*/)>;
+struct Prog {
+  std::vector<Op> ops;
+  int run(hipStream_t s, int step) const {
+    for (const Op& o : ops) RC(o(s, step));
+    return DTP_OK;
+  }
+};
+
+struct ResW {
+  NormW n1, n2;
+  ConvW c1, c2, sc;
+  bool has_sc = false;
+  int temb_off = -1;  // offset of this block's (conv1.bias + time_emb_proj(...)) slice in the step-bias table
+};
+struct XfW {
+  NormW gn, ln1, ln2, ln3;
+  ConvW proj_in, qkv, out1, q2, kv2, out2, ff1, ff2, proj_out;
+  int kv_index = -1;  // which cross-attention K/V buffer
+};
+struct VaeAttnW {
+  NormW gn;
+  ConvW qk, out;
+  f16* wv = nullptr;  // [512][512] plain fp16 (used as the activation-side operand: V^T = Wv x^T)
+  float* bv = nullptr;
+};
+
+struct UNetW {
+  ConvW conv_in, conv_out, t1, t2, tproj;  // tproj: all 22 time_emb_proj stacked
+  NormW norm_out;
+  ResW down_res[4][2], mid_res[2], up_res[4][3];
+  XfW down_xf[3][2], mid_xf, up_xf[4][3];
+  ConvW down_conv[3], up_conv[3];
+  int temb_total = 0;
+};
+struct VaeW {
+  ConvW enc_in, enc_out, dec_in, dec_out;
+  ResW enc_res[4][2], enc_mid[2], dec_mid[2], dec_res[4][3];
+  ConvW enc_down[3], dec_up[3];
+  VaeAttnW enc_attn, dec_attn;
+  NormW enc_norm_out, dec_norm_out;
+  float *quant_w = nullptr, *quant_b = nullptr, *pquant_w = nullptr, *pquant_b = nullptr;  // fp32 8x8 / 4x4
+};
+struct ClipLayerW {
+  NormW ln1, ln2;
+  ConvW qkv, out, fc1, fc2;
+};
+struct PencBlockW {
+  NormW n1, n3;
+  ConvW qkv, out, ff1, ff2;
+};
+struct ImgEncW {
+  ConvW patch;  // 32x32 s32 conv as a [768][3072] GEMM
+  float *cls_pos = nullptr;   // class_embedding + pos[0]   fp32 [768]
+  float *pos = nullptr;       // pos[1..49] fp32 [49][768]
+  NormW pre_ln, post_ln, final_ln;
+  ClipLayerW layers[12];
+  PencBlockW blocks[3][4];
+  ConvW proj_out;
+  float* uncond = nullptr;    // [14][768]
+  float* pos_emb = nullptr;   // [14][768] (image_encoder.py:54-56)
+  bool present = false;
+};
+
+struct Pool {
+  struct Block { char* p; size_t bytes; bool free; };
+  std::vector<Block> blocks;
+  size_t total = 0;
+};
+
+struct UNetProg {
+  int N = 0;          // UNet batch (3B or 2B)
+  Prog kv, main;
+  f16* in16 = nullptr;     // [N][h][w][16] input (latent 0-3, mask 4, masked latents 5-8, zero 9-15)
+  f16* ctx16 = nullptr;    // [N][14][768]
+  float* out32 = nullptr;  // [N][h][w][4]
+  std::vector<f16*> kvbuf; // 16 x [N*14][2C]
+};
+struct VaeEncProg {
+  int B = 0;
+  Prog main;
+  f16* in8 = nullptr;       // [B][R][R][8]
+  float* moments = nullptr; // [B][h][w][8] (conv_out output, before quant_conv)
+};
+struct VaeDecProg {
+  int B = 0;
+  Prog main;
+  f16* in8 = nullptr;     // [B][h][w][8] (after post_quant_conv)
+  float* out32 = nullptr; // [B][R][R][4] (3 used)
+};
+
+struct StampGraph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int nodes = 0;
+};
+
+struct Ctx {
+  int device = 0, R = 0, h = 0, maxB = 1, num_cu = 256;
+  bool finalized = false;
+  std::unordered_map<std::string, Staged> staged;
+
+  // weight arena (zero-initialised chunks, bump allocated)
+  std::vector<void*> chunks;
+  char* cur = nullptr;
+  size_t cur_left = 0, arena_total = 0;
+  Pool pool;
+  std::vector<void*> persistent;  // dedicated buffers (freed at destroy)
+  f16* zero = nullptr;
+  float* ws = nullptr;            // shared split-K / GroupNorm workspace
+  size_t ws_bytes = 0, ws_need = 0;
+
+  UNetW unet;
+  VaeW vae;
+  ImgEncW ienc;
+
+  // programs keyed by batch
+  std::map<int, UNetProg> unet_progs;
+  std::map<int, VaeEncProg> enc_progs;
+  std::map<int, VaeDecProg> dec_progs;
+
+  // step-bias table for the current step set: fp32 [nsteps][temb_total]
+  float* temb_table = nullptr;
+  int temb_rows = 0;         // capacity
+  f16* temb_sin = nullptr;   // [rows][320]
+  f16 *temb_h1 = nullptr, *temb_h2 = nullptr;  // [rows][1280]
+  int sched_steps = -1;      // step count the table/coefficients were built for
+
+  // conditioning
+  float* cond32 = nullptr;   // [2][14][768] : cond, uncond
+  float* brush32 = nullptr;  // [3][R][R]
+  bool have_cond = false;
+  unsigned long long cond_version = 0;
+  std::map<int, unsigned long long> kv_version;  // per UNet batch: conditioning version its K/V were built from
+
+  // stamp state
+  float* x32 = nullptr;       // [maxB][h][w][4] current latent (fp32, NHWC)
+  float* canvas32 = nullptr;  // [maxB][4][R][R] copy of the canvas (for compositing inside the graph-free tail)
+  float* alpha_tmp = nullptr; // dilation scratch [2][maxB][R][R]
+  float* stamp_params = nullptr;  // device: per-step DDIM coefficients + weights
+  std::map<long long, StampGraph> graphs;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int last_evals = 0, last_nodes = 0;
+  bool use_graph = true;
+  bool exec_imgenc_ready = false;
+};
+
+// ---- engine.hip
+int ctx_arena_alloc(Ctx* c, size_t bytes, void** out);
+int ctx_pool_get(Ctx* c, size_t bytes, void** out);
+void ctx_pool_put(Ctx* c, void* p);
+int ctx_persistent(Ctx* c, size_t bytes, void** out, bool zero);
+const Staged* ctx_find(Ctx* c, const std::string& name);
+int ctx_fetch_host(Ctx* c, const std::string& name, std::vector<float>& out);
+int ctx_upload_f32(Ctx* c, const std::vector<float>& v, float** out);
+int load_norm(Ctx* c, const std::string& name, NormW& n);
+// conv weight [Cout][Cin][k][k] -> packed; cin_pad = padded input channels (>= Cin, multiple of 8)
+int load_conv(Ctx* c, const std::string& name, ConvW& w, int cin_pad = 0, bool bias = true);
+// stacked linear: rows of several [n_i][K] matrices one after another; geglu packs the [a|gate] tile order
+int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bias, bool geglu = false);
+int load_plain_f16(Ctx* c, const std::string& name, f16** out);  // unpadded fp16 copy of a matrix
+
+// ---- builder helpers (engine.hip): every function appends ops to `prog` and returns planned buffers
+struct Builder {
+  Ctx* c;
+  Prog* prog;
+  T alloc(int B, int H, int W, int C);
+  void release(const T& t);
+  int gn(const T& x, const NormW& n, float eps, bool silu, T& y);
+  int ln(const T& x, const NormW& n, T& y);
+  // conv3x3; bias_step_off >= 0 selects the per-step bias slice from the temb table instead of w.b
+  int conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, int Ho, int Wo, const T* resid, int bias_step_off,
+            T& y, int extra_flags = 0, void* out_override = nullptr, int ldc_override = 0);
+  int linear(const T& x, const ConvW& w, const T* resid, int flags, T& y);
+  int attention(const T& q, const T& k, const T& v, int heads, int Sq, int Skv, int Bn, T& o);
+  int concat(const T& a, const T& b, T& y);
+  int resnet(const T& x, const ResW& w, float eps, bool temb, T& y);
+};
+
+int build_unet_prog(Ctx* c, int N, UNetProg& up);
+int build_vae_enc_prog(Ctx* c, int B, VaeEncProg& p);
+int build_vae_dec_prog(Ctx* c, int B, VaeDecProg& p);
+int load_unet_weights(Ctx* c);
+int load_vae_weights(Ctx* c);
+int ensure_ws(Ctx* c);
+int ensure_temb(Ctx* c, const std::vector<float>& timesteps);  // fills temb_table rows 0..n-1
+
+// ---- stamp.hip
+int stamp_init(Ctx* c);

@@ -1,19 +1,391 @@
-// placeholder while the engine is being written (replaced in the next commit)
-#include "../../include/dtp.h"
-#include "common.h"
-extern "C" {
-#define NI { dtp_set_error("not implemented yet"); return DTP_ERR_STATE; }
-int dtp_create(int, int, int, dtp_ctx**) NI
-void dtp_destroy(dtp_ctx*) {}
-int dtp_load_tensor(dtp_ctx*, const char*, const float*, int, const int64_t*, int) NI
-int dtp_finalize_weights(dtp_ctx*) NI
-int dtp_vae_encode(dtp_ctx*, const float*, const float*, float*, int, dtp_stream) NI
-int dtp_unet(dtp_ctx*, const float*, float, const void*, float*, int, dtp_stream) NI
-int dtp_vae_decode(dtp_ctx*, const float*, float*, int, dtp_stream) NI
-int dtp_set_brush(dtp_ctx*, const float*, int, int, float*, dtp_stream) NI
-int dtp_set_conditioning(dtp_ctx*, const float*, const float*, const float*, dtp_stream) NI
-int dtp_get_conditioning(dtp_ctx*, float*, float*, dtp_stream) NI
-int dtp_stamp(dtp_ctx*, const float*, const dtp_settings*, const float*, const float*, void*, int, dtp_stream) NI
-int dtp_last_stamp_times(dtp_ctx*, float*) NI
-int dtp_last_stamp_info(dtp_ctx*, int*, int*) NI
+// Engine core: context lifecycle, weight staging + packing, static buffer planning, op builder.
+#include "engine.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+static size_t up_to(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------- memory
+int ctx_arena_alloc(Ctx* c, size_t bytes, void** out) {
+  bytes = up_to(bytes, 256);
+  if (bytes > c->cur_left) {
+    const size_t chunk = std::max(bytes, (size_t)512 << 20);
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, chunk));
+    HIP_CHECK(hipMemset(p, 0, chunk));
+    c->chunks.push_back(p);
+    c->cur = (char*)p;
+    c->cur_left = chunk;
+    c->arena_total += chunk;
+  }
+  *out = c->cur;
+  c->cur += bytes;
+  c->cur_left -= bytes;
+  return DTP_OK;
 }
+
+int ctx_pool_get(Ctx* c, size_t bytes, void** out) {
+  bytes = up_to(bytes, 4096);
+  int best = -1;
+  for (size_t i = 0; i < c->pool.blocks.size(); ++i) {
+    const Pool::Block& b = c->pool.blocks[i];
+    if (b.free && b.bytes >= bytes && b.bytes <= bytes + bytes / 2 + (1 << 20) &&
+        (best < 0 || b.bytes < c->pool.blocks[best].bytes))
+      best = (int)i;
+  }
+  if (best < 0) {
+    // +256 KiB slack: operand tiles may over-read up to 127 rows past the last valid row
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, bytes + (256 << 10)));
+    HIP_CHECK(hipMemset(p, 0, bytes + (256 << 10)));
+    c->pool.blocks.push_back({(char*)p, bytes, false});
+    c->pool.total += bytes;
+    *out = p;
+    return DTP_OK;
+  }
+  c->pool.blocks[best].free = false;
+  *out = c->pool.blocks[best].p;
+  return DTP_OK;
+}
+
+void ctx_pool_put(Ctx* c, void* p) {
+  for (auto& b : c->pool.blocks)
+    if (b.p == (char*)p) { b.free = true; return; }
+}
+
+int ctx_persistent(Ctx* c, size_t bytes, void** out, bool zero) {
+  void* p = nullptr;
+  HIP_CHECK(hipMalloc(&p, bytes + (256 << 10)));
+  if (zero) HIP_CHECK(hipMemset(p, 0, bytes + (256 << 10)));
+  c->persistent.push_back(p);
+  *out = p;
+  return DTP_OK;
+}
+
+const Staged* ctx_find(Ctx* c, const std::string& name) {
+  auto it = c->staged.find(name);
+  return it == c->staged.end() ? nullptr : &it->second;
+}
+
+int ctx_fetch_host(Ctx* c, const std::string& name, std::vector<float>& out) {
+  const Staged* s = ctx_find(c, name);
+  if (!s) { dtp_set_error("missing tensor '%s'", name.c_str()); return DTP_ERR_MISSING; }
+  out.resize(s->n);
+  HIP_CHECK(hipMemcpy(out.data(), s->d, s->n * sizeof(float), hipMemcpyDeviceToHost));
+  return DTP_OK;
+}
+
+int ctx_upload_f32(Ctx* c, const std::vector<float>& v, float** out) {
+  void* p;
+  RC(ctx_arena_alloc(c, v.size() * sizeof(float), &p));
+  HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = (float*)p;
+  return DTP_OK;
+}
+
+// ---------------------------------------------------------------- weight loaders
+int load_norm(Ctx* c, const std::string& name, NormW& n) {
+  const Staged *g = ctx_find(c, name + ".weight"), *b = ctx_find(c, name + ".bias");
+  if (!g || !b) { dtp_set_error("missing norm '%s'", name.c_str()); return DTP_ERR_MISSING; }
+  void *pg, *pb;
+  RC(ctx_arena_alloc(c, g->n * 4, &pg));
+  RC(ctx_arena_alloc(c, b->n * 4, &pb));
+  HIP_CHECK(hipMemcpy(pg, g->d, g->n * 4, hipMemcpyDeviceToDevice));
+  HIP_CHECK(hipMemcpy(pb, b->d, b->n * 4, hipMemcpyDeviceToDevice));
+  n.g = (float*)pg; n.b = (float*)pb; n.c = (int)g->n;
+  return DTP_OK;
+}
+
+int load_conv(Ctx* c, const std::string& name, ConvW& w, int cin_pad, bool bias) {
+  const Staged* s = ctx_find(c, name + ".weight");
+  if (!s) { dtp_set_error("missing weight '%s.weight'", name.c_str()); return DTP_ERR_MISSING; }
+  const int cout = (int)s->shape[0], cin = (int)s->shape[1];
+  const int taps = s->shape.size() == 4 ? (int)(s->shape[2] * s->shape[3]) : 1;
+  if (cin_pad <= 0) cin_pad = (int)up_to(cin, 8);
+  w.cout = cout; w.cin = cin_pad; w.taps = taps; w.K = taps * cin_pad; w.ldw = (int)up_to(w.K, 64);
+  void* p;
+  RC(ctx_arena_alloc(c, up_to(cout, 128) * (size_t)w.ldw * 2, &p));
+  w.w = (f16*)p;
+  RC(dtp_launch_pack_conv_weight(s->d, w.w, cout, cin, cin_pad, taps, w.ldw, 0));
+  w.b = nullptr;
+  if (bias) {
+    const Staged* b = ctx_find(c, name + ".bias");
+    if (!b) { dtp_set_error("missing bias '%s.bias'", name.c_str()); return DTP_ERR_MISSING; }
+    void* pb;
+    RC(ctx_arena_alloc(c, b->n * 4, &pb));
+    HIP_CHECK(hipMemcpy(pb, b->d, b->n * 4, hipMemcpyDeviceToDevice));
+    w.b = (float*)pb;
+  }
+  return DTP_OK;
+}
+
+int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bias, bool geglu) {
+  int N = 0, K = -1;
+  for (const auto& nm : names) {
+    const Staged* s = ctx_find(c, nm + ".weight");
+    if (!s) { dtp_set_error("missing weight '%s.weight'", nm.c_str()); return DTP_ERR_MISSING; }
+    const int k = (int)(s->n / s->shape[0]);
+    if (K >= 0 && k != K) { dtp_set_error("stacked linear '%s': K mismatch", nm.c_str()); return DTP_ERR_ARG; }
+    K = k;
+    N += (int)s->shape[0];
+  }
+  w.cout = N; w.cin = K; w.taps = 1; w.K = K; w.ldw = (int)up_to(K, 64);
+  void* p;
+  RC(ctx_arena_alloc(c, up_to(N, 128) * (size_t)w.ldw * 2, &p));
+  w.w = (f16*)p;
+  std::vector<int> map;
+  int* dmap = nullptr;
+  if (geglu) {
+    if (names.size() != 1 || N % 256) { dtp_set_error("geglu pack: bad shape"); return DTP_ERR_ARG; }
+    map.resize(N);
+    for (int f = 0; f < N / 2; ++f) {
+      map[f] = (f / 64) * 128 + (f % 64);
+      map[N / 2 + f] = (f / 64) * 128 + 64 + (f % 64);
+    }
+    HIP_CHECK(hipMalloc(&dmap, N * sizeof(int)));
+    HIP_CHECK(hipMemcpy(dmap, map.data(), N * sizeof(int), hipMemcpyHostToDevice));
+  }
+  int row = 0;
+  for (const auto& nm : names) {
+    const Staged* s = ctx_find(c, nm + ".weight");
+    const int n = (int)s->shape[0];
+    RC(dtp_launch_pack_linear_weight(s->d, w.w + (size_t)row * w.ldw, n, K, w.ldw, dmap, 0));
+    row += n;
+  }
+  if (dmap) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(dmap)); }
+  w.b = nullptr;
+  if (bias) {
+    std::vector<float> all;
+    for (const auto& nm : names) {
+      std::vector<float> b;
+      if (ctx_find(c, nm + ".bias")) RC(ctx_fetch_host(c, nm + ".bias", b));
+      else b.assign((size_t)ctx_find(c, nm + ".weight")->shape[0], 0.f);
+      all.insert(all.end(), b.begin(), b.end());
+    }
+    if (geglu) {
+      std::vector<float> perm(all.size());
+      for (size_t i = 0; i < all.size(); ++i) perm[map[i]] = all[i];
+      all.swap(perm);
+    }
+    all.resize(up_to(all.size(), 128), 0.f);
+    RC(ctx_upload_f32(c, all, &w.b));
+  }
+  return DTP_OK;
+}
+
+int load_plain_f16(Ctx* c, const std::string& name, f16** out) {
+  const Staged* s = ctx_find(c, name);
+  if (!s) { dtp_set_error("missing tensor '%s'", name.c_str()); return DTP_ERR_MISSING; }
+  void* p;
+  RC(ctx_arena_alloc(c, s->n * 2, &p));
+  RC(dtp_launch_f32_to_f16(s->d, (f16*)p, (long long)s->n, 0));
+  *out = (f16*)p;
+  return DTP_OK;
+}
+
+int ensure_ws(Ctx* c) {
+  if (c->ws_need <= c->ws_bytes) return DTP_OK;
+  HIP_CHECK(hipDeviceSynchronize());
+  if (c->ws) HIP_CHECK(hipFree(c->ws));
+  c->ws = nullptr;
+  HIP_CHECK(hipMalloc(&c->ws, c->ws_need));
+  c->ws_bytes = c->ws_need;
+  // captured graphs hold the old workspace pointer: drop them, they are re-captured on next use
+  for (auto& g : c->graphs) {
+    if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+    if (g.second.graph) (void)hipGraphDestroy(g.second.graph);
+  }
+  c->graphs.clear();
+  return DTP_OK;
+}
+
+// ---------------------------------------------------------------- builder
+T Builder::alloc(int B, int H, int W, int C) {
+  T t;
+  t.B = B; t.H = H; t.W = W; t.C = C; t.ld = C;
+  void* p = nullptr;
+  if (ctx_pool_get(c, (size_t)B * H * W * C * sizeof(f16), &p) != DTP_OK) p = nullptr;
+  t.p = (f16*)p;
+  return t;
+}
+void Builder::release(const T& t) { ctx_pool_put(c, t.p); }
+
+int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
+  y = alloc(x.B, x.H, x.W, x.C);
+  if (!y.p) return DTP_ERR_HIP;
+  Ctx* cc = c;
+  cc->ws_need = std::max(cc->ws_need, dtp_groupnorm_ws_bytes(x.B, x.H * x.W, x.C, 32));
+  const T xx = x, yy = y;
+  const NormW nn = n;
+  prog->ops.push_back([=](hipStream_t s, int) {
+    return dtp_launch_groupnorm(xx.p, xx.ld, yy.p, yy.ld, nn.g, nn.b, cc->ws, xx.B, xx.H * xx.W, xx.C, 32, eps, silu ? 1 : 0, s);
+  });
+  return DTP_OK;
+}
+
+int Builder::ln(const T& x, const NormW& n, T& y) {
+  y = alloc(x.B, x.H, x.W, x.C);
+  if (!y.p) return DTP_ERR_HIP;
+  const T xx = x, yy = y;
+  const NormW nn = n;
+  prog->ops.push_back([=](hipStream_t s, int) {
+    return dtp_launch_layernorm(xx.p, xx.ld, yy.p, yy.ld, nn.g, nn.b, (int)xx.rows(), xx.C, 1e-5f, s);
+  });
+  return DTP_OK;
+}
+
+static int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off) {
+  int tile = 0;
+  dtp_gemm_pick(p, &tile, c->num_cu);
+  c->ws_need = std::max(c->ws_need, dtp_gemm_workspace_bytes(p));
+  p.zero = c->zero;
+  prog->ops.push_back([=](hipStream_t s, int step) {
+    GemmParams q = p;
+    q.part = c->ws;
+    if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;
+    return dtp_launch_gemm(q, tile, s);
+  });
+  return DTP_OK;
+}
+
+int Builder::conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, int Ho, int Wo, const T* resid,
+                   int bias_step_off, T& y, int extra_flags, void* out_override, int ldc_override) {
+  if (x.C != w.cin || w.taps != 9) { dtp_set_error("conv3: channel mismatch %d vs %d", x.C, w.cin); return DTP_ERR_ARG; }
+  GemmParams p = {};
+  p.A = x.p; p.W = w.w;
+  p.M = x.B * Ho * Wo; p.N = w.cout; p.K = w.K;
+  p.lda = x.ld; p.ldw = w.ldw;
+  p.nkb = w.ldw / 64;
+  p.Hi = x.H; p.Wi = x.W; p.Ho = Ho; p.Wo = Wo; p.Cin = w.cin; p.stride = stride; p.pad = pad;
+  p.flags = GF_CONV3 | (ups ? GF_UPS2 : 0) | extra_flags;
+  if (out_override) {
+    y = T();
+    y.p = (f16*)out_override; y.B = x.B; y.H = Ho; y.W = Wo; y.C = w.cout; y.ld = ldc_override;
+  } else {
+    y = alloc(x.B, Ho, Wo, w.cout);
+    if (!y.p) return DTP_ERR_HIP;
+  }
+  p.C = y.p; p.ldc = y.ld;
+  if (w.b || bias_step_off >= 0) { p.flags |= GF_BIAS; p.bias = w.b; }
+  if (resid) { p.flags |= GF_RESID; p.R = resid->p; p.ldr = resid->ld; }
+  return push_gemm(c, prog, p, bias_step_off);
+}
+
+int Builder::linear(const T& x, const ConvW& w, const T* resid, int flags, T& y) {
+  if (x.C != w.K || w.taps != 1) { dtp_set_error("linear: K mismatch %d vs %d", x.C, w.K); return DTP_ERR_ARG; }
+  GemmParams p = {};
+  p.A = x.p; p.W = w.w;
+  p.M = (int)x.rows(); p.N = w.cout; p.K = w.K;
+  p.lda = x.ld; p.ldw = w.ldw; p.nkb = w.ldw / 64;
+  p.flags = flags;
+  y = alloc(x.B, x.H, x.W, (flags & GF_GEGLU) ? w.cout / 2 : w.cout);
+  if (!y.p) return DTP_ERR_HIP;
+  p.C = y.p; p.ldc = y.ld;
+  if (w.b) { p.flags |= GF_BIAS; p.bias = w.b; }
+  if (resid) { p.flags |= GF_RESID; p.R = resid->p; p.ldr = resid->ld; }
+  return push_gemm(c, prog, p, -1);
+}
+
+int Builder::attention(const T& q, const T& k, const T& v, int heads, int Sq, int Skv, int Bn, T& o) {
+  o = alloc(Bn, 1, Sq, q.C);
+  if (!o.p) return DTP_ERR_HIP;
+  AttnParams a;
+  a.Q = q.p; a.K = k.p; a.V = v.p; a.O = o.p;
+  a.ldq = q.ld; a.ldk = k.ld; a.ldv = v.ld; a.ldo = o.ld;
+  a.B = Bn; a.H = heads; a.Sq = Sq; a.Skv = Skv; a.D = q.C / heads;
+  a.qbs = (long long)Sq * q.ld; a.kbs = (long long)Skv * k.ld; a.vbs = (long long)Skv * v.ld; a.obs = (long long)Sq * o.ld;
+  a.scale = 1.0f / sqrtf((float)a.D);
+  prog->ops.push_back([=](hipStream_t s, int) { return dtp_launch_attention(a, s); });
+  return DTP_OK;
+}
+
+int Builder::concat(const T& a, const T& b, T& y) {
+  y = alloc(a.B, a.H, a.W, a.C + b.C);
+  if (!y.p) return DTP_ERR_HIP;
+  const T aa = a, bb = b, yy = y;
+  prog->ops.push_back([=](hipStream_t s, int) {
+    return dtp_launch_concat_channels(aa.p, aa.ld, aa.C, bb.p, bb.ld, bb.C, yy.p, yy.ld, aa.rows(), s);
+  });
+  return DTP_OK;
+}
+
+int Builder::resnet(const T& x, const ResW& w, float eps, bool temb, T& y) {
+  T t1, h, t2, sc;
+  RC(gn(x, w.n1, eps, true, t1));
+  RC(conv3(t1, w.c1, 1, 1, false, x.H, x.W, nullptr, temb ? w.temb_off : -1, h));
+  release(t1);
+  RC(gn(h, w.n2, eps, true, t2));
+  release(h);
+  const T* res = &x;
+  if (w.has_sc) {
+    RC(linear(x, w.sc, nullptr, 0, sc));
+    res = &sc;
+  }
+  RC(conv3(t2, w.c2, 1, 1, false, x.H, x.W, res, -1, y));
+  release(t2);
+  if (w.has_sc) release(sc);
+  return DTP_OK;
+}
+
+// ---------------------------------------------------------------- C ABI: lifecycle + weights
+extern "C" {
+
+int dtp_create(int device, int resolution, int max_batch, dtp_ctx** out) {
+  if (!out || resolution < 64 || resolution % 64 || max_batch < 1 || max_batch > 64) {
+    dtp_set_error("dtp_create: resolution must be a positive multiple of 64, 1 <= max_batch <= 64");
+    return DTP_ERR_ARG;
+  }
+  HIP_CHECK(hipSetDevice(device));
+  Ctx* c = new Ctx();
+  c->device = device; c->R = resolution; c->h = resolution / 8; c->maxB = max_batch;
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  c->num_cu = prop.multiProcessorCount;
+  void* z;
+  HIP_CHECK(hipMalloc(&z, 4096));
+  HIP_CHECK(hipMemset(z, 0, 4096));
+  c->zero = (f16*)z;
+  for (int i = 0; i < 4; ++i) HIP_CHECK(hipEventCreate(&c->ev[i]));
+  *out = (dtp_ctx*)c;
+  return DTP_OK;
+}
+
+void dtp_destroy(dtp_ctx* ctx) {
+  Ctx* c = (Ctx*)ctx;
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (auto& g : c->graphs) {
+    if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+    if (g.second.graph) (void)hipGraphDestroy(g.second.graph);
+  }
+  for (auto& s : c->staged) (void)hipFree(s.second.d);
+  for (void* p : c->chunks) (void)hipFree(p);
+  for (auto& b : c->pool.blocks) (void)hipFree(b.p);
+  for (void* p : c->persistent) (void)hipFree(p);
+  if (c->ws) (void)hipFree(c->ws);
+  if (c->zero) (void)hipFree(c->zero);
+  for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  delete c;
+}
+
+int dtp_load_tensor(dtp_ctx* ctx, const char* name, const float* data, int is_device, const int64_t* shape, int ndim) {
+  Ctx* c = (Ctx*)ctx;
+  if (!c || !name || !data || ndim < 1 || ndim > 4) { dtp_set_error("dtp_load_tensor: bad argument"); return DTP_ERR_ARG; }
+  if (c->finalized) { dtp_set_error("dtp_load_tensor: weights already finalized"); return DTP_ERR_STATE; }
+  HIP_CHECK(hipSetDevice(c->device));
+  Staged s;
+  s.n = 1;
+  for (int i = 0; i < ndim; ++i) { s.shape.push_back(shape[i]); s.n *= (size_t)shape[i]; }
+  HIP_CHECK(hipMalloc(&s.d, std::max<size_t>(s.n * 4, 16)));
+  HIP_CHECK(hipMemcpy(s.d, data, s.n * 4, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  auto it = c->staged.find(name);
+  if (it != c->staged.end()) { (void)hipFree(it->second.d); c->staged.erase(it); }
+  c->staged.emplace(name, std::move(s));
+  return DTP_OK;
+}
+
+}  // extern "C"

@@ -18,8 +18,6 @@
 // Workgroup ids are remapped so each XCD (private L2) owns a contiguous range of tiles.
 #include "common.h"
 
-#define GF_MFAST 512  // internal: tile_m varies fastest (blocks adjacent in id share the W panel)
-
 namespace {
 
 __device__ __forceinline__ void glds16(const void* src, void* lds_uniform) {
@@ -253,6 +251,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = x[e] / (1.0f + __expf(-1.702f * x[e]));
     }
+    if (fl & GF_SILU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = x[e] / (1.0f + __expf(-x[e]));
+    }
     if (full && vec_ok) {
       if (fl & GF_RESID) {
         const f16x8 r = *(const f16x8*)(p.R + (size_t)m * p.ldr + n);
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     if (fl & GF_BIAS_M) x += p.bias[m];
     if (fl & GF_GELU) x = gelu_erf(x);
     if (fl & GF_QUICKGELU) x = x / (1.0f + __expf(-1.702f * x));
+    if (fl & GF_SILU) x = x / (1.0f + __expf(-x));
     if (fl & GF_RESID) x += (float)p.R[(size_t)m * p.ldr + n];
     if (fl & GF_OUT_F32) ((float*)p.C)[(size_t)m * p.ldc + n] = x;
     else ((f16*)p.C)[(size_t)m * p.ldc + n] = (f16)x;
@@ -298,16 +301,18 @@ int launch_tile(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   constexpr int lds = 2 * (BM + BN) * 128;
   static_assert(lds >= BM * (BN + 8) * 2, "staging tile must fit in the pipeline buffers");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
   hipLaunchKernelGGL((gemm_kernel<BM, BN>), dim3(tiles, 1, p.splits), dim3(256), lds, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
 }  // namespace
+
+void dtp_gemm_init() {  // raise the dynamic-LDS limit once, outside any stream capture
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 192 * 128);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 192 * 128);
+}
 
 size_t dtp_gemm_workspace_bytes(const GemmParams& p) {
   return p.splits > 1 ? (size_t)p.splits * p.M * p.N * sizeof(float) : 0;

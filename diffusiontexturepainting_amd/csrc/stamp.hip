@@ -1,0 +1,436 @@
+// The stamp: everything TRTConditionalInpainter.generate_raw / InpaintPipeline.infer do around the
+// three networks, as fused HIP kernels + hipGraph replay.
+// Reference: trt_inference/trt_model.py:90-121, handler.py:25-33,55-56, model_base.py:51-58,
+// inpaint_pipeline.py:39-153, stable_diffusion_pipeline.py:340-355,407-484, utilities.py:370-529.
+#include <math.h>
+
+#include "engine.h"
+
+int get_unet_prog(Ctx* c, int N, UNetProg** out);
+int get_enc_prog(Ctx* c, int B, VaeEncProg** out);
+int get_dec_prog(Ctx* c, int B, VaeDecProg** out);
+int launch_vae_sample(Ctx* c, const float* mom, const float* eps, float* out, int B, float scale, hipStream_t s);
+int launch_post_quant(Ctx* c, const float* z, int nhwc, float in_scale, f16* out, int B, hipStream_t s);
+int load_imgenc_weights(Ctx* c);
+void dtp_gemm_init();
+
+#define VAE_SCALE 0.18215f
+
+// ---------------------------------------------------------------- DDIM tables (host, fp32 like torch)
+// utilities.py:383-388 (betas, cumprod), :432-439 (timesteps), :416 (gather), :397 (final alpha).
+extern "C" int dtp_ddim_tables(int steps, int64_t* timesteps, float* alphas, float* final_alpha) {
+  if (steps < 1 || steps > 1000) { dtp_set_error("ddim: steps %d outside 1..1000", steps); return DTP_ERR_ARG; }
+  const int T = 1000;
+  static float full[1000];
+  static bool have = false;
+  if (!have) {
+    const float start = (float)sqrt(0.00085), end = (float)sqrt(0.012);
+    const float step = (end - start) / (float)(T - 1);
+    double acc = 1.0;  // torch's CPU cumprod accumulates float in double and rounds every output
+    for (int i = 0; i < T; ++i) {
+      const float l = (i < T / 2) ? start + step * (float)i : end - step * (float)(T - 1 - i);
+      const float beta = l * l;
+      acc *= (double)(1.0f - beta);
+      full[i] = (float)acc;
+    }
+    have = true;
+  }
+  const int ratio = T / steps;
+  for (int i = 0; i < steps; ++i) {
+    const int64_t t = (int64_t)(steps - 1 - i) * ratio + 1;
+    if (timesteps) timesteps[i] = t;
+    if (alphas) alphas[i] = full[t];
+  }
+  if (final_alpha) *final_alpha = full[0];
+  return DTP_OK;
+}
+
+// ---------------------------------------------------------------- kernels
+namespace {
+
+// separable flat dilation (kornia.morphology.dilation with ones(pad,pad), geodesic border):
+// out[i] = max over [i - pad/2, i + pad - pad/2 - 1] clipped to the image.
+__global__ void dilate_row_kernel(const float* __restrict__ canvas, float* __restrict__ tmp, int B, int R, int lo, int hi) {
+  const long long total = (long long)B * R * R;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % R);
+    const long long by = i / R;
+    const int y = (int)(by % R), b = (int)(by / R);
+    const float* a = canvas + ((size_t)b * 4 + 3) * R * R + (size_t)y * R;
+    float m = -1e4f;
+    for (int xx = max(0, x - lo); xx <= min(R - 1, x + hi); ++xx) m = fmaxf(m, a[xx]);
+    tmp[i] = m;
+  }
+}
+__global__ void dilate_col_kernel(const float* __restrict__ tmp, float* __restrict__ out, int B, int R, int lo, int hi) {
+  const long long total = (long long)B * R * R;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % R);
+    const long long by = i / R;
+    const int y = (int)(by % R), b = (int)(by / R);
+    const float* a = tmp + (size_t)b * R * R + x;
+    float m = -1e4f;
+    for (int yy = max(0, y - lo); yy <= min(R - 1, y + hi); ++yy) m = fmaxf(m, a[(size_t)yy * R]);
+    out[i] = m;
+  }
+}
+
+// trt_model.py:103-109 + handler.py:25-33: canvas -> VAE-encoder inputs (NHWC f16, 8 channels,
+// batch [masked x B | context x B]) and the two latent-resolution masks (nearest, 1 = paint).
+__global__ void prep_kernel(const float* __restrict__ canvas, const float* __restrict__ brush, const float* __restrict__ dil,
+                            f16* __restrict__ enc_in, float* __restrict__ masks, int B, int R) {
+  const int HW = R * R, h = R / 8;
+  const long long total = (long long)B * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / HW), pix = (int)(i - (long long)b * HW);
+    const float* cb = canvas + (size_t)b * 4 * HW;
+    const float a = cb[3 * HW + pix];
+    const float hint = 1.0f - dil[i];
+    f16x8 m8, c8;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float img = cb[ch * HW + pix] * 2.0f - 1.0f;
+      const float masked = img * a;
+      const float src = brush[ch * HW + pix] * 2.0f - 1.0f;
+      m8[ch] = (f16)masked;
+      c8[ch] = (f16)(masked + src * hint);
+    }
+#pragma unroll
+    for (int ch = 3; ch < 8; ++ch) m8[ch] = c8[ch] = (f16)0.f;
+    *(f16x8*)(enc_in + i * 8) = m8;
+    *(f16x8*)(enc_in + ((size_t)B * HW + i) * 8) = c8;
+    const int y = pix / R, x = pix - y * R;
+    if ((y & 7) == 0 && (x & 7) == 0) {  // F.interpolate(size=(h,w)) default 'nearest': src = dst * 8
+      const size_t o = (size_t)b * h * h + (size_t)(y >> 3) * h + (x >> 3);
+      masks[o] = 1.0f - a;
+      masks[(size_t)B * h * h + o] = 1.0f - fminf(fmaxf(a + hint, 0.f), 1.f);
+    }
+  }
+}
+
+// UNet input assembly (inpaint_pipeline.py:116,136; sdp:423-427): branch-major [uncond|cond|tg] x B.
+__global__ void assemble_kernel(const float* __restrict__ lat_nchw, const float* __restrict__ masks,
+                                const float* __restrict__ ml, f16* __restrict__ in16, float* __restrict__ x32, int B, int HWl,
+                                int NB) {
+  const long long total = (long long)B * HWl;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / HWl), p = (int)(i - (long long)b * HWl);
+    float x[4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      if (lat_nchw) {
+        x[ch] = lat_nchw[((size_t)b * 4 + ch) * HWl + p];  // * init_noise_sigma (= 1.0)
+        x32[i * 4 + ch] = x[ch];
+      } else {
+        x[ch] = x32[i * 4 + ch];  // mid-loop switch to the 2-branch program: keep the running latent
+      }
+    }
+    for (int br = 0; br < NB; ++br) {
+      const int src = (br < 2) ? b : B + b;  // branches 0,1: masked image; branch 2: context image
+      f16x8 lo, hi;
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) lo[ch] = (f16)x[ch];
+      lo[4] = (f16)masks[(size_t)src * HWl + p];
+      lo[5] = (f16)ml[((size_t)src * 4 + 0) * HWl + p];
+      lo[6] = (f16)ml[((size_t)src * 4 + 1) * HWl + p];
+      lo[7] = (f16)ml[((size_t)src * 4 + 2) * HWl + p];
+      hi[0] = (f16)ml[((size_t)src * 4 + 3) * HWl + p];
+#pragma unroll
+      for (int ch = 1; ch < 8; ++ch) hi[ch] = (f16)0.f;
+      f16* o = in16 + ((size_t)(br * B + b) * HWl + p) * 16;
+      *(f16x8*)o = lo;
+      *(f16x8*)(o + 8) = hi;
+    }
+  }
+}
+
+// guidance combine + DDIM eta=0 step + refresh of the latent channels of the UNet input
+// (sdp:419-420,449-455; utilities.py:463-503).  params: [0]=cfg [1]=tg [2]=tg_steps, then 4 per step.
+__global__ void step_kernel(const float* __restrict__ eps_out, float* __restrict__ x32, f16* __restrict__ in16,
+                            const float* __restrict__ params, int step_index, int B, int HWl, int NB) {
+  const float cfg = params[0];
+  const float tg = ((float)step_index > params[2] - 1.0f) ? 0.f : params[1];
+  const float* k = params + 4 + 4 * step_index;
+  const float sqrt_beta_t = k[0], sqrt_alpha_t = k[1], sqrt_alpha_prev = k[2], sqrt_beta_prev = k[3];
+  const long long total = (long long)B * HWl * 4;
+  const size_t bs = (size_t)B * HWl * 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const float u = eps_out[i], c = eps_out[bs + i];
+    float e = u + cfg * (c - u);
+    if (NB == 3) e += tg * (eps_out[2 * bs + i] - c);
+    const float x = x32[i];
+    const float x0 = (x - sqrt_beta_t * e) / sqrt_alpha_t;
+    const float xn = sqrt_alpha_prev * x0 + sqrt_beta_prev * e;
+    x32[i] = xn;
+    const long long pix = i >> 2;
+    const int ch = (int)(i & 3);
+    for (int br = 0; br < NB; ++br) in16[((size_t)br * B * HWl + pix) * 16 + ch] = (f16)xn;
+  }
+}
+
+// inpaint_pipeline.py:148 clamp, optional alpha composite (model_base.py:56-58) and the truncating
+// u8 conversion (handler.py:55-56).
+__global__ void finish_kernel(const float* __restrict__ dec, const float* __restrict__ canvas, void* __restrict__ out, int B,
+                              int HW, int composite, int u8) {
+  const long long total = (long long)B * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / HW), pix = (int)(i - (long long)b * HW);
+    const float a = composite ? canvas[((size_t)b * 4 + 3) * HW + pix] : 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      float v = fminf(fmaxf(dec[i * 4 + ch] / 2.0f + 0.5f, 0.f), 1.f);
+      if (composite) v = canvas[((size_t)b * 4 + ch) * HW + pix] * a + v * (1.0f - a);
+      if (u8) ((unsigned char*)out)[i * 3 + ch] = (unsigned char)(v * 255.0f);
+      else ((float*)out)[((size_t)b * 3 + ch) * HW + pix] = v;
+    }
+  }
+}
+
+// ctx16[n][14][768]: branch 0 <- uncond, branches 1.. <- cond  (inpaint_pipeline.py:140)
+__global__ void build_ctx_kernel(const float* __restrict__ cond2, f16* __restrict__ ctx16, int B, int NB) {
+  const int per = 14 * 768;
+  const long long total = (long long)NB * B * per;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i / per), j = (int)(i - (long long)n * per);
+    const int br = n / B;
+    ctx16[i] = (f16)cond2[(br == 0 ? per : 0) + j];
+  }
+}
+
+inline int nblk(long long total) { return (int)std::min<long long>((total + 255) / 256, 4096); }
+
+}  // namespace
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP)
+
+int stamp_init(Ctx* c) {
+  void* p;
+  const size_t hw = (size_t)c->h * c->h, RR = (size_t)c->R * c->R;
+  RC(ctx_persistent(c, c->maxB * hw * 4 * 4, &p, true)); c->x32 = (float*)p;
+  RC(ctx_persistent(c, c->maxB * 4 * RR * 4, &p, true)); c->canvas32 = (float*)p;
+  RC(ctx_persistent(c, 2 * c->maxB * RR * 4, &p, true)); c->alpha_tmp = (float*)p;
+  RC(ctx_persistent(c, (4 + 4 * 1000) * 4, &p, true)); c->stamp_params = (float*)p;
+  RC(ctx_persistent(c, 2 * 14 * 768 * 4, &p, true)); c->cond32 = (float*)p;
+  RC(ctx_persistent(c, 3 * RR * 4, &p, true)); c->brush32 = (float*)p;
+  return DTP_OK;
+}
+
+struct StampBufs {  // per-batch persistent staging
+  float *masks = nullptr, *ml = nullptr, *lat = nullptr, *eps = nullptr;
+};
+static std::map<std::pair<Ctx*, int>, StampBufs> g_bufs;
+
+static int get_bufs(Ctx* c, int B, StampBufs** out) {
+  auto key = std::make_pair(c, B);
+  auto it = g_bufs.find(key);
+  if (it == g_bufs.end()) {
+    StampBufs sb;
+    void* p;
+    const size_t hw = (size_t)c->h * c->h;
+    RC(ctx_persistent(c, 2 * B * hw * 4, &p, true)); sb.masks = (float*)p;
+    RC(ctx_persistent(c, 2 * B * 4 * hw * 4, &p, true)); sb.ml = (float*)p;
+    RC(ctx_persistent(c, B * 4 * hw * 4, &p, true)); sb.lat = (float*)p;
+    RC(ctx_persistent(c, 2 * B * 4 * hw * 4, &p, true)); sb.eps = (float*)p;
+    it = g_bufs.emplace(key, sb).first;
+  }
+  *out = &it->second;
+  return DTP_OK;
+}
+
+// run `body` on stream s, replaying a captured hipGraph when possible
+template <class F>
+static int run_stage(Ctx* c, long long key, hipStream_t s, F body) {
+  if (!c->use_graph || s == nullptr) return body(s);
+  auto it = c->graphs.find(key);
+  if (it == c->graphs.end()) {
+    StampGraph g;
+    HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = body(s);
+    hipError_t e = hipStreamEndCapture(s, &g.graph);
+    if (rc != DTP_OK) { if (g.graph) (void)hipGraphDestroy(g.graph); return rc; }
+    if (e != hipSuccess) { dtp_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return DTP_ERR_HIP; }
+    size_t n = 0;
+    (void)hipGraphGetNodes(g.graph, nullptr, &n);
+    g.nodes = (int)n;
+    HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+    it = c->graphs.emplace(key, g).first;
+  }
+  c->last_nodes += it->second.nodes;
+  HIP_CHECK(hipGraphLaunch(it->second.exec, s));
+  return DTP_OK;
+}
+
+extern "C" {
+
+int dtp_finalize_weights(dtp_ctx* ctx) {
+  Ctx* c = (Ctx*)ctx;
+  if (!c) { dtp_set_error("dtp_finalize_weights: null handle"); return DTP_ERR_ARG; }
+  if (c->finalized) { dtp_set_error("dtp_finalize_weights: already finalized"); return DTP_ERR_STATE; }
+  HIP_CHECK(hipSetDevice(c->device));
+  dtp_gemm_init();
+  RC(load_unet_weights(c));
+  RC(load_vae_weights(c));
+  bool has_clip = false;
+  for (auto& kv : c->staged)
+    if (kv.first.rfind("clip.", 0) == 0) { has_clip = true; break; }
+  if (has_clip) RC(load_imgenc_weights(c));
+  HIP_CHECK(hipDeviceSynchronize());
+  for (auto& s : c->staged) (void)hipFree(s.second.d);
+  c->staged.clear();
+  RC(stamp_init(c));
+  c->finalized = true;
+  return DTP_OK;
+}
+
+int dtp_set_conditioning(dtp_ctx* ctx, const float* cond, const float* uncond, const float* brush, dtp_stream s_) {
+  Ctx* c = (Ctx*)ctx;
+  hipStream_t s = (hipStream_t)s_;
+  if (!c || !c->finalized || !cond || !uncond || !brush) { dtp_set_error("dtp_set_conditioning: bad state/argument"); return DTP_ERR_STATE; }
+  HIP_CHECK(hipSetDevice(c->device));
+  HIP_CHECK(hipMemcpyAsync(c->cond32, cond, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(c->cond32 + 14 * 768, uncond, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(c->brush32, brush, (size_t)3 * c->R * c->R * 4, hipMemcpyDeviceToDevice, s));
+  c->have_cond = true;
+  ++c->cond_version;
+  return DTP_OK;
+}
+
+int dtp_get_conditioning(dtp_ctx* ctx, float* cond, float* uncond, dtp_stream s_) {
+  Ctx* c = (Ctx*)ctx;
+  hipStream_t s = (hipStream_t)s_;
+  if (!c || !c->have_cond) { dtp_set_error("dtp_get_conditioning: no brush set"); return DTP_ERR_STATE; }
+  HIP_CHECK(hipMemcpyAsync(cond, c->cond32, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(uncond, c->cond32 + 14 * 768, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
+  return DTP_OK;
+}
+
+int dtp_stamp(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const float* latents, const float* vae_eps,
+              void* out, int B, dtp_stream s_) {
+  Ctx* c = (Ctx*)ctx;
+  hipStream_t s = (hipStream_t)s_;
+  if (!c || !c->finalized) { dtp_set_error("dtp_stamp: weights not finalized"); return DTP_ERR_STATE; }
+  if (!c->have_cond) { dtp_set_error("dtp_stamp: no brush set (call dtp_set_brush / dtp_set_conditioning)"); return DTP_ERR_STATE; }
+  if (!canvas || !st || !latents || !out || B < 1 || B > c->maxB) { dtp_set_error("dtp_stamp: bad argument (B=%d, max %d)", B, c->maxB); return DTP_ERR_ARG; }
+  if (st->steps < 2 || st->steps > 1000) { dtp_set_error("dtp_stamp: steps=%d outside 2..1000", st->steps); return DTP_ERR_ARG; }
+  if (st->context_pad < 1) { dtp_set_error("dtp_stamp: context_pad must be >= 1"); return DTP_ERR_ARG; }
+  HIP_CHECK(hipSetDevice(c->device));
+  const int R = c->R, h = c->h, HW = R * R, HWl = h * h;
+  const int steps = st->steps, E = steps - 1;
+  // the third (texture-guided) branch contributes nothing once its coefficient is 0: skip it (bit-identical)
+  const int tg_evals = (st->tg_weight == 0.0f) ? 0 : std::max(0, std::min(E, st->tg_steps));
+
+  UNetProg *u3 = nullptr, *u2 = nullptr;
+  VaeEncProg* enc;
+  VaeDecProg* dec;
+  StampBufs* sb;
+  if (tg_evals > 0) RC(get_unet_prog(c, 3 * B, &u3));
+  if (tg_evals < E) RC(get_unet_prog(c, 2 * B, &u2));
+  RC(get_enc_prog(c, 2 * B, &enc));
+  RC(get_dec_prog(c, B, &dec));
+  RC(get_bufs(c, B, &sb));
+
+  // ---- schedule tables (update_infer_settings, inpaint_pipeline.py:39-50): rebuilt when the step count changes
+  if (c->sched_steps != steps) {
+    HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<int64_t> ts(steps);
+    std::vector<float> al(steps);
+    float fin;
+    RC(dtp_ddim_tables(steps, ts.data(), al.data(), &fin));
+    std::vector<float> tsf;
+    for (int i = 1; i < steps; ++i) tsf.push_back((float)ts[i]);  // timesteps[1:] (sdp:348-355)
+    RC(ensure_temb(c, tsf));
+    std::vector<float> k(4 * E);
+    for (int i = 0; i < E; ++i) {
+      const int idx = 1 + i;
+      const float a_t = al[idx], a_prev = (idx + 1 < steps) ? al[idx + 1] : fin;
+      k[4 * i + 0] = sqrtf(1.0f - a_t);
+      k[4 * i + 1] = sqrtf(a_t);
+      k[4 * i + 2] = sqrtf(a_prev);
+      k[4 * i + 3] = sqrtf(1.0f - a_prev);
+    }
+    HIP_CHECK(hipMemcpy(c->stamp_params + 4, k.data(), k.size() * 4, hipMemcpyHostToDevice));
+    c->sched_steps = steps;
+  }
+  const float hdr[4] = {st->cfg_weight, st->tg_weight, (float)st->tg_steps, 0.f};
+  HIP_CHECK(hipMemcpyAsync(c->stamp_params, hdr, sizeof(hdr), hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipStreamSynchronize(s));  // hdr is a stack buffer
+
+  // ---- cross-attention K/V for the current brush
+  for (UNetProg* up : {u3, u2}) {
+    if (!up) continue;
+    if (c->kv_version[up->N] != c->cond_version) {
+      const int NB = up->N / B;
+      hipLaunchKernelGGL(build_ctx_kernel, dim3(nblk((long long)up->N * 14 * 768)), dim3(256), 0, s, c->cond32, up->ctx16, B, NB);
+      RC(up->kv.run(s, 0));
+      c->kv_version[up->N] = c->cond_version;
+    }
+  }
+
+  c->last_nodes = 0;
+  c->last_evals = E;
+  HIP_CHECK(hipEventRecord(c->ev[0], s));
+  // ---- stage 0: pre-processing + both VAE encodes (one batch-2B pass)
+  HIP_CHECK(hipMemcpyAsync(sb->lat, latents, (size_t)B * 4 * HWl * 4, hipMemcpyDeviceToDevice, s));
+  if (vae_eps) HIP_CHECK(hipMemcpyAsync(sb->eps, vae_eps, (size_t)2 * B * 4 * HWl * 4, hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(c->canvas32, canvas, (size_t)B * 4 * HW * 4, hipMemcpyDeviceToDevice, s));
+  const int lo = st->context_pad / 2, hi = st->context_pad - st->context_pad / 2 - 1;
+  hipLaunchKernelGGL(dilate_row_kernel, dim3(nblk((long long)B * HW)), dim3(256), 0, s, c->canvas32, c->alpha_tmp, B, R, lo, hi);
+  hipLaunchKernelGGL(dilate_col_kernel, dim3(nblk((long long)B * HW)), dim3(256), 0, s, c->alpha_tmp,
+                     c->alpha_tmp + (size_t)c->maxB * HW, B, R, lo, hi);
+  const int first_nb = tg_evals > 0 ? 3 : 2;
+  UNetProg* first = tg_evals > 0 ? u3 : u2;
+  RC(run_stage(c, ((long long)B << 32) | (vae_eps ? 2 : 0) | (first_nb == 3 ? 1 : 0) | (1LL << 60), s, [&](hipStream_t q) -> int {
+    hipLaunchKernelGGL(prep_kernel, dim3(nblk((long long)B * HW)), dim3(256), 0, q, c->canvas32, c->brush32,
+                       c->alpha_tmp + (size_t)c->maxB * HW, enc->in8, sb->masks, B, R);
+    RC(enc->main.run(q, 0));
+    RC(launch_vae_sample(c, enc->moments, vae_eps ? sb->eps : nullptr, sb->ml, 2 * B, VAE_SCALE, q));
+    hipLaunchKernelGGL(assemble_kernel, dim3(nblk((long long)B * HWl)), dim3(256), 0, q, sb->lat, sb->masks, sb->ml, first->in16,
+                       c->x32, B, HWl, first_nb);
+    return LAUNCH_OK();
+  }));
+  HIP_CHECK(hipEventRecord(c->ev[1], s));
+  // ---- stage 1: the denoise loop
+  RC(run_stage(c, ((long long)B << 32) | ((long long)steps << 12) | tg_evals | (2LL << 60), s, [&](hipStream_t q) -> int {
+    for (int i = 0; i < E; ++i) {
+      UNetProg* up = (i < tg_evals) ? u3 : u2;
+      const int NB = (i < tg_evals) ? 3 : 2;
+      if (i == tg_evals && i > 0) {
+        // switching to the 2-branch program: its input needs mask/masked-latent channels + current x
+        hipLaunchKernelGGL(assemble_kernel, dim3(nblk((long long)B * HWl)), dim3(256), 0, q, (const float*)nullptr, sb->masks,
+                           sb->ml, up->in16, c->x32, B, HWl, 2);
+      }
+      RC(up->main.run(q, i));
+      hipLaunchKernelGGL(step_kernel, dim3(nblk((long long)B * HWl * 4)), dim3(256), 0, q, up->out32, c->x32, up->in16,
+                         c->stamp_params, i, B, HWl, NB);
+    }
+    return LAUNCH_OK();
+  }));
+  HIP_CHECK(hipEventRecord(c->ev[2], s));
+  // ---- stage 2: latents / 0.18215 -> VAE decode -> clamp (+ composite, u8)
+  RC(run_stage(c, ((long long)B << 32) | (3LL << 60), s, [&](hipStream_t q) -> int {
+    RC(launch_post_quant(c, c->x32, 1, 1.0f / VAE_SCALE, dec->in8, B, q));
+    return dec->main.run(q, 0);
+  }));
+  hipLaunchKernelGGL(finish_kernel, dim3(nblk((long long)B * HW)), dim3(256), 0, s, dec->out32, c->canvas32, out, B, HW,
+                     st->composite, st->output_u8);
+  HIP_CHECK(hipEventRecord(c->ev[3], s));
+  return LAUNCH_OK();
+}
+
+int dtp_last_stamp_times(dtp_ctx* ctx, float ms[3]) {
+  Ctx* c = (Ctx*)ctx;
+  if (!c || !ms) return DTP_ERR_ARG;
+  HIP_CHECK(hipEventSynchronize(c->ev[3]));
+  for (int i = 0; i < 3; ++i) HIP_CHECK(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+  return DTP_OK;
+}
+
+int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes) {
+  Ctx* c = (Ctx*)ctx;
+  if (!c) return DTP_ERR_ARG;
+  if (unet_evals) *unet_evals = c->last_evals;
+  if (graph_nodes) *graph_nodes = c->last_nodes;
+  return DTP_OK;
+}
+
+}  // extern "C"

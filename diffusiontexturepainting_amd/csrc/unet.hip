@@ -1,0 +1,342 @@
+// SD-1.5-inpainting UNet on the libdtp kernels: weight loading (with LoRA merge), the static
+// launch program, and the `unet` engine entry point.
+// Reference: trt_inference/models.py:1017-1139 (model + LoRA merge + engine I/O); topology
+// SURVEY.md Appendix A.1.
+#include <math.h>
+
+#include "engine.h"
+
+static const int CH[4] = {320, 640, 1280, 1280};
+
+static int load_res(Ctx* c, const std::string& p, ResW& w, bool temb, int& temb_off_acc, std::vector<std::string>* tnames) {
+  RC(load_norm(c, p + ".norm1", w.n1));
+  RC(load_conv(c, p + ".conv1", w.c1));
+  RC(load_norm(c, p + ".norm2", w.n2));
+  RC(load_conv(c, p + ".conv2", w.c2));
+  w.has_sc = ctx_find(c, p + ".conv_shortcut.weight") != nullptr;
+  if (w.has_sc) RC(load_conv(c, p + ".conv_shortcut", w.sc));
+  if (temb) {
+    w.temb_off = temb_off_acc;
+    temb_off_acc += w.c1.cout;
+    tnames->push_back(p);
+  }
+  return DTP_OK;
+}
+
+static int load_xf(Ctx* c, const std::string& p, XfW& w, int& kv_counter) {
+  const std::string t = p + ".transformer_blocks.0";
+  RC(load_norm(c, p + ".norm", w.gn));
+  RC(load_conv(c, p + ".proj_in", w.proj_in));
+  RC(load_norm(c, t + ".norm1", w.ln1));
+  RC(load_norm(c, t + ".norm2", w.ln2));
+  RC(load_norm(c, t + ".norm3", w.ln3));
+  RC(load_linear(c, {t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"}, w.qkv, false));
+  RC(load_linear(c, {t + ".attn1.to_out.0"}, w.out1, true));
+  RC(load_linear(c, {t + ".attn2.to_q"}, w.q2, false));
+  RC(load_linear(c, {t + ".attn2.to_k", t + ".attn2.to_v"}, w.kv2, false));
+  RC(load_linear(c, {t + ".attn2.to_out.0"}, w.out2, true));
+  RC(load_linear(c, {t + ".ff.net.0.proj"}, w.ff1, true, true));
+  RC(load_linear(c, {t + ".ff.net.2"}, w.ff2, true));
+  RC(load_conv(c, p + ".proj_out", w.proj_out));
+  w.kv_index = kv_counter++;
+  return DTP_OK;
+}
+
+// W += 1.0 * up @ down for q/k/v/out of every attention module that has LoRA tensors staged
+// (trt_inference/models.py:1070-1086).  Operates on the staged fp32 tensors, before packing.
+static int merge_lora(Ctx* c) {
+  std::vector<std::string> keys;
+  for (auto& kv : c->staged)
+    if (kv.first.rfind("lora.", 0) == 0 && kv.first.find("_lora.down.weight") != std::string::npos) keys.push_back(kv.first);
+  for (const std::string& k : keys) {
+    // lora.<module>.processor.<proj>_lora.down.weight
+    const size_t pp = k.find(".processor.");
+    if (pp == std::string::npos) continue;
+    const std::string module = k.substr(5, pp - 5);
+    const size_t ps = pp + 11, pe = k.find("_lora.down.weight");
+    const std::string proj = k.substr(ps, pe - ps);
+    const std::string upk = "lora." + module + ".processor." + proj + "_lora.up.weight";
+    const std::string tgt = "unet." + module + (proj == "to_out" ? ".to_out.0.weight" : "." + proj + ".weight");
+    const Staged *dn = ctx_find(c, k), *up = ctx_find(c, upk), *w = ctx_find(c, tgt);
+    if (!up || !w) { dtp_set_error("LoRA: missing '%s' or target '%s'", upk.c_str(), tgt.c_str()); return DTP_ERR_MISSING; }
+    const int rank = (int)dn->shape[0], K = (int)dn->shape[1], N = (int)up->shape[0];
+    if ((int)w->shape[0] != N || (int)w->shape[1] != K || (int)up->shape[1] != rank) {
+      dtp_set_error("LoRA: shape mismatch for '%s'", tgt.c_str());
+      return DTP_ERR_ARG;
+    }
+    RC(dtp_launch_lora_merge(w->d, up->d, dn->d, N, K, rank, 1.0f, 0));
+  }
+  HIP_CHECK(hipDeviceSynchronize());
+  return DTP_OK;
+}
+
+int load_unet_weights(Ctx* c) {
+  RC(merge_lora(c));
+  UNetW& u = c->unet;
+  const std::string P = "unet.";
+  int toff = 0, kvn = 0;
+  std::vector<std::string> tn;
+  RC(load_conv(c, P + "conv_in", u.conv_in, 16));
+  RC(load_linear(c, {P + "time_embedding.linear_1"}, u.t1, true));
+  RC(load_linear(c, {P + "time_embedding.linear_2"}, u.t2, true));
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 2; ++j) {
+      RC(load_res(c, P + "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), u.down_res[i][j], true, toff, &tn));
+      if (i < 3) RC(load_xf(c, P + "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), u.down_xf[i][j], kvn));
+    }
+    if (i < 3) RC(load_conv(c, P + "down_blocks." + std::to_string(i) + ".downsamplers.0.conv", u.down_conv[i]));
+  }
+  RC(load_res(c, P + "mid_block.resnets.0", u.mid_res[0], true, toff, &tn));
+  RC(load_xf(c, P + "mid_block.attentions.0", u.mid_xf, kvn));
+  RC(load_res(c, P + "mid_block.resnets.1", u.mid_res[1], true, toff, &tn));
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      RC(load_res(c, P + "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), u.up_res[i][j], true, toff, &tn));
+      if (i > 0) RC(load_xf(c, P + "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), u.up_xf[i][j], kvn));
+    }
+    if (i < 3) RC(load_conv(c, P + "up_blocks." + std::to_string(i) + ".upsamplers.0.conv", u.up_conv[i]));
+  }
+  RC(load_norm(c, P + "conv_norm_out", u.norm_out));
+  RC(load_conv(c, P + "conv_out", u.conv_out));
+  // all time_emb_proj stacked into one [temb_total][1280] GEMM; its bias also carries conv1.bias so the
+  // per-step table row is directly the conv1 bias of every ResBlock
+  u.temb_total = toff;
+  std::vector<std::string> names;
+  for (auto& p : tn) names.push_back(p + ".time_emb_proj");
+  RC(load_linear(c, names, u.tproj, false));
+  std::vector<float> bias;
+  for (auto& p : tn) {
+    std::vector<float> a, b;
+    RC(ctx_fetch_host(c, p + ".time_emb_proj.bias", a));
+    RC(ctx_fetch_host(c, p + ".conv1.bias", b));
+    for (size_t i = 0; i < a.size(); ++i) bias.push_back(a[i] + b[i]);
+  }
+  bias.resize((bias.size() + 127) / 128 * 128, 0.f);
+  RC(ctx_upload_f32(c, bias, &u.tproj.b));
+  return DTP_OK;
+}
+
+// timestep embedding -> per-step conv1 bias rows.  Host sinusoid (flip_sin_to_cos, shift 0), then
+// three GEMMs: linear_1+SiLU, linear_2+SiLU (every consumer applies SiLU first), stacked projections.
+int ensure_temb(Ctx* c, const std::vector<float>& timesteps) {
+  const int n = (int)timesteps.size();
+  if (n > 1000) { dtp_set_error("temb: too many timesteps"); return DTP_ERR_ARG; }
+  if (n > c->temb_rows) {
+    const int rows = 1000;  // fixed capacity: captured graphs keep pointers into this table
+    void* p;
+    RC(ctx_persistent(c, (size_t)rows * c->unet.temb_total * 4, &p, true)); c->temb_table = (float*)p;
+    RC(ctx_persistent(c, (size_t)rows * 320 * 2, &p, true)); c->temb_sin = (f16*)p;
+    RC(ctx_persistent(c, (size_t)rows * 1280 * 2, &p, true)); c->temb_h1 = (f16*)p;
+    RC(ctx_persistent(c, (size_t)rows * 1280 * 2, &p, true)); c->temb_h2 = (f16*)p;
+    c->temb_rows = rows;
+  }
+  std::vector<f16> sin_tab((size_t)n * 320);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < 160; ++j) {
+      const float f = expf(-logf(10000.0f) * (float)j / 160.0f);
+      const float a = timesteps[i] * f;
+      sin_tab[(size_t)i * 320 + j] = (f16)cosf(a);
+      sin_tab[(size_t)i * 320 + 160 + j] = (f16)sinf(a);
+    }
+  HIP_CHECK(hipMemcpy(c->temb_sin, sin_tab.data(), sin_tab.size() * 2, hipMemcpyHostToDevice));
+  auto gemm = [&](const f16* A, const ConvW& w, void* C, int flags) -> int {
+    GemmParams p = {};
+    p.A = A; p.W = w.w; p.C = C; p.bias = w.b; p.zero = c->zero;
+    p.M = n; p.N = w.cout; p.K = w.K; p.lda = w.K; p.ldw = w.ldw; p.ldc = w.cout; p.nkb = w.ldw / 64;
+    p.flags = flags | GF_BIAS;
+    p.splits = 1; p.kb_per_split = p.nkb;
+    return dtp_launch_gemm(p, p.M > 64 ? 0 : 3, 0);
+  };
+  RC(gemm(c->temb_sin, c->unet.t1, c->temb_h1, GF_SILU));
+  RC(gemm(c->temb_h1, c->unet.t2, c->temb_h2, GF_SILU));
+  RC(gemm(c->temb_h2, c->unet.tproj, c->temb_table, GF_OUT_F32));
+  HIP_CHECK(hipDeviceSynchronize());
+  return DTP_OK;
+}
+
+static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up, T& out) {
+  const int C = x.C, S = x.H * x.W, N = x.B;
+  T t, y, n1, qkv, a, y2, n2, q2, a2, y3, n3, f, y4;
+  RC(b.gn(x, w.gn, 1e-6f, false, t));
+  RC(b.linear(t, w.proj_in, nullptr, 0, y));
+  b.release(t);
+  RC(b.ln(y, w.ln1, n1));
+  RC(b.linear(n1, w.qkv, nullptr, 0, qkv));
+  b.release(n1);
+  T q = qkv, k = qkv, v = qkv;
+  q.C = k.C = v.C = C;
+  k.p += C; v.p += 2 * C;
+  RC(b.attention(q, k, v, 8, S, S, N, a));
+  b.release(qkv);
+  a.B = x.B; a.H = x.H; a.W = x.W;
+  RC(b.linear(a, w.out1, &y, 0, y2));
+  b.release(a); b.release(y);
+  RC(b.ln(y2, w.ln2, n2));
+  RC(b.linear(n2, w.q2, nullptr, 0, q2));
+  b.release(n2);
+  T kk, vv;
+  kk.p = up.kvbuf[w.kv_index]; kk.B = N; kk.H = 1; kk.W = 14; kk.C = C; kk.ld = 2 * C;
+  vv = kk; vv.p += C;
+  RC(b.attention(q2, kk, vv, 8, S, 14, N, a2));
+  b.release(q2);
+  a2.B = x.B; a2.H = x.H; a2.W = x.W;
+  RC(b.linear(a2, w.out2, &y2, 0, y3));
+  b.release(a2); b.release(y2);
+  RC(b.ln(y3, w.ln3, n3));
+  RC(b.linear(n3, w.ff1, nullptr, GF_GEGLU, f));
+  b.release(n3);
+  RC(b.linear(f, w.ff2, &y3, 0, y4));
+  b.release(f); b.release(y3);
+  RC(b.linear(y4, w.proj_out, &x, 0, out));
+  b.release(y4);
+  return DTP_OK;
+}
+
+int build_unet_prog(Ctx* c, int N, UNetProg& up) {
+  const UNetW& u = c->unet;
+  const int h = c->h;
+  up.N = N;
+  void* p;
+  RC(ctx_persistent(c, (size_t)N * h * h * 16 * 2, &p, true)); up.in16 = (f16*)p;
+  RC(ctx_persistent(c, (size_t)N * 14 * 768 * 2, &p, true)); up.ctx16 = (f16*)p;
+  RC(ctx_persistent(c, (size_t)N * h * h * 4 * 4, &p, true)); up.out32 = (float*)p;
+  // ---- cross-attention K/V of the 16 transformer blocks (depends only on the conditioning)
+  std::vector<const XfW*> xfs;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) xfs.push_back(&u.down_xf[i][j]);
+  xfs.push_back(&u.mid_xf);
+  for (int i = 1; i < 4; ++i) for (int j = 0; j < 3; ++j) xfs.push_back(&u.up_xf[i][j]);
+  up.kvbuf.assign(xfs.size(), nullptr);
+  {
+    Builder b{c, &up.kv};
+    T ctx;
+    ctx.p = up.ctx16; ctx.B = N; ctx.H = 1; ctx.W = 14; ctx.C = 768; ctx.ld = 768;
+    for (const XfW* w : xfs) {
+      RC(ctx_persistent(c, (size_t)N * 14 * w->kv2.cout * 2, &p, true));
+      up.kvbuf[w->kv_index] = (f16*)p;
+      GemmParams g = {};
+      g.A = ctx.p; g.W = w->kv2.w; g.C = p;
+      g.M = N * 14; g.N = w->kv2.cout; g.K = 768; g.lda = 768; g.ldw = w->kv2.ldw; g.ldc = w->kv2.cout; g.nkb = w->kv2.ldw / 64;
+      g.zero = c->zero;
+      g.splits = 1; g.kb_per_split = g.nkb;
+      up.kv.ops.push_back([=](hipStream_t s, int) { return dtp_launch_gemm(g, 3, s); });
+    }
+  }
+  // ---- main program
+  Builder b{c, &up.main};
+  T x0;
+  x0.p = up.in16; x0.B = N; x0.H = h; x0.W = h; x0.C = 16; x0.ld = 16;
+  T x;
+  RC(b.conv3(x0, u.conv_in, 1, 1, false, h, h, nullptr, -1, x));
+  std::vector<T> skips;
+  skips.push_back(x);
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 2; ++j) {
+      T y;
+      RC(b.resnet(x, u.down_res[i][j], 1e-5f, true, y));
+      // x stays alive as a skip (it was pushed) -- do not release
+      x = y;
+      if (i < 3) {
+        T z;
+        RC(transformer(b, x, u.down_xf[i][j], up, z));
+        b.release(x);
+        x = z;
+      }
+      skips.push_back(x);
+    }
+    if (i < 3) {
+      T y;
+      RC(b.conv3(x, u.down_conv[i], 2, 1, false, x.H / 2, x.W / 2, nullptr, -1, y));
+      x = y;
+      skips.push_back(x);
+    }
+  }
+  {
+    T y, z, w2;
+    RC(b.resnet(x, u.mid_res[0], 1e-5f, true, y));  // x is skips.back(): keep
+    RC(transformer(b, y, u.mid_xf, up, z));
+    b.release(y);
+    RC(b.resnet(z, u.mid_res[1], 1e-5f, true, w2));
+    b.release(z);
+    x = w2;
+  }
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      T skip = skips.back();
+      skips.pop_back();
+      T cat, y;
+      RC(b.concat(x, skip, cat));
+      b.release(x); b.release(skip);
+      RC(b.resnet(cat, u.up_res[i][j], 1e-5f, true, y));
+      b.release(cat);
+      x = y;
+      if (i > 0) {
+        T z;
+        RC(transformer(b, x, u.up_xf[i][j], up, z));
+        b.release(x);
+        x = z;
+      }
+    }
+    if (i < 3) {
+      T y;
+      RC(b.conv3(x, u.up_conv[i], 1, 1, true, x.H * 2, x.W * 2, nullptr, -1, y));
+      b.release(x);
+      x = y;
+    }
+  }
+  T t, o;
+  RC(b.gn(x, u.norm_out, 1e-5f, true, t));
+  b.release(x);
+  RC(b.conv3(t, u.conv_out, 1, 1, false, h, h, nullptr, -1, o, GF_OUT_F32, up.out32, 4));
+  b.release(t);
+  return ensure_ws(c);
+}
+
+__global__ void nhwc4_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW, int ldx) {
+  const long long total = (long long)B * C * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int hw = (int)(i % HW);
+    const long long bc = i / HW;
+    const int ch = (int)(bc % C), b = (int)(bc / C);
+    y[i] = x[((size_t)b * HW + hw) * ldx + ch];
+  }
+}
+
+int launch_nhwc_f32_to_nchw(const float* x, float* y, int B, int C, int HW, int ldx, hipStream_t s) {
+  long long total = (long long)B * C * HW;
+  int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(nhwc4_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, x, y, B, C, HW, ldx);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
+
+int get_unet_prog(Ctx* c, int N, UNetProg** out) {
+  auto it = c->unet_progs.find(N);
+  if (it == c->unet_progs.end()) {
+    UNetProg& up = c->unet_progs[N];
+    RC(build_unet_prog(c, N, up));
+    *out = &up;
+    return DTP_OK;
+  }
+  *out = &it->second;
+  return DTP_OK;
+}
+
+extern "C" int dtp_unet(dtp_ctx* ctx, const float* sample, float timestep, const void* ctx_f16, float* out, int N,
+                        dtp_stream s_) {
+  Ctx* c = (Ctx*)ctx;
+  hipStream_t s = (hipStream_t)s_;
+  if (!c || !c->finalized) { dtp_set_error("dtp_unet: weights not finalized"); return DTP_ERR_STATE; }
+  if (N < 1 || N > 3 * c->maxB) { dtp_set_error("dtp_unet: batch %d outside 1..%d", N, 3 * c->maxB); return DTP_ERR_ARG; }
+  HIP_CHECK(hipSetDevice(c->device));
+  UNetProg* up;
+  RC(get_unet_prog(c, N, &up));
+  const int hw = c->h * c->h;
+  HIP_CHECK(hipStreamSynchronize(s));
+  RC(ensure_temb(c, {timestep}));
+  c->sched_steps = -1;  // the table no longer holds a stamp schedule
+  RC(dtp_launch_nchw_f32_to_nhwc_f16(sample, up->in16, N, 9, hw, 16, s));
+  HIP_CHECK(hipMemcpyAsync(up->ctx16, ctx_f16, (size_t)N * 14 * 768 * 2, hipMemcpyDeviceToDevice, s));
+  c->kv_version[N] = 0;  // K/V now belong to the caller's conditioning
+  RC(up->kv.run(s, 0));
+  RC(up->main.run(s, 0));
+  return launch_nhwc_f32_to_nchw(up->out32, out, N, 4, hw, 4, s);
+}

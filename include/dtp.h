@@ -89,6 +89,11 @@ typedef struct {
 int dtp_stamp(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const float* latents, const float* vae_eps,
               void* out, int B, dtp_stream s);
 
+/* Host-only: the DDIM tables dtp_stamp uses for `steps` inference steps -- timesteps[steps] (descending,
+ * +1 offset), alphas_cumprod gathered at those timesteps, and final_alpha_cumprod
+ * (DDIMScheduler.set_timesteps/configure, utilities.py:408-439).  Any pointer may be NULL. */
+int dtp_ddim_tables(int steps, int64_t* timesteps, float* alphas, float* final_alpha);
+
 /* per-stage GPU time of the last dtp_stamp on this handle, ms (print_summary,
  * stable_diffusion_pipeline.py:486-503): [0]=pre+vae_encoder x2, [1]=denoise loop, [2]=vae decode+post.
  * Blocks until the stamp has finished. */
@@ -114,7 +119,7 @@ typedef struct {
   int splits;        /* 0 = heuristic; >=1 = forced split-K factor */
 } dtp_gemm_desc;
 enum { DTP_GF_BIAS = 1, DTP_GF_BIAS_M = 2, DTP_GF_RESID = 4, DTP_GF_GEGLU = 8, DTP_GF_GELU = 64, DTP_GF_QUICKGELU = 128,
-       DTP_GF_OUT_F32 = 256 };
+       DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512 };
 
 int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s);
 /* w f32 [N][K] -> out f16 [rows][ldw] (caller zero-fills out); geglu=1 applies the [a|gate] tile packing */
