@@ -21,15 +21,13 @@ __device__ __forceinline__ float wave_max(float v) {
 // at most two groups (channels-per-group >= 4 on this path), so it accumulates in registers.
 __global__ void gn_stats_kernel(const f16* __restrict__ x, int ldx, float* __restrict__ partial, int HW, int C, int cpg,
                                 int groups, int pix_per_chunk) {
-  __shared__ float red[64 * 2];
+  __shared__ float part[1024 * 4];  // per-thread (s0, q0, s1, q1); reduced in a fixed order (deterministic)
   const int nch = C >> 3;
   const int cc = threadIdx.x % nch, prow = threadIdx.x / nch, rows = blockDim.x / nch;
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-  for (int i = threadIdx.x; i < groups * 2; i += blockDim.x) red[i] = 0.f;
-  __syncthreads();
   const int c0 = cc * 8;
   const int g0 = c0 / cpg;
-  const int split = min(8, (g0 + 1) * cpg - c0);  // elements [0,split) belong to g0, the rest to g0+1.. (cpg>=4)
+  const int split = min(8, (g0 + 1) * cpg - c0);  // elements [0,split) belong to g0, the rest to g0+1 (cpg>=4)
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
   const int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
   const f16* base = x + (size_t)b * HW * ldx + c0;
@@ -41,15 +39,25 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int ldx, float* __res
       if (e < split) { s0 += f; q0 += f * f; } else { s1 += f; q1 += f * f; }
     }
   }
-  atomicAdd(&red[g0 * 2], s0);
-  atomicAdd(&red[g0 * 2 + 1], q0);
-  if (split < 8) {  // cpg == 4: [4,8) is exactly group g0+1; cpg >= 8: the tail is shorter than a group
-    atomicAdd(&red[(g0 + 1) * 2], s1);
-    atomicAdd(&red[(g0 + 1) * 2 + 1], q1);
-  }
+  part[threadIdx.x * 4 + 0] = s0;
+  part[threadIdx.x * 4 + 1] = q0;
+  part[threadIdx.x * 4 + 2] = s1;
+  part[threadIdx.x * 4 + 3] = q1;
   __syncthreads();
   float* out = partial + ((size_t)b * nchunk + chunk) * groups * 2;
-  for (int i = threadIdx.x; i < groups * 2; i += blockDim.x) out[i] = red[i];
+  for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+    float s = 0.f, q = 0.f;
+    const int cfirst = (g * cpg) >> 3, clast = ((g + 1) * cpg - 1) >> 3;
+    for (int c = cfirst; c <= clast; ++c) {
+      const int sel = ((c * 8) / cpg == g) ? 0 : 2;  // this chunk's first or second group
+      for (int r = 0; r < rows; ++r) {
+        s += part[(r * nch + c) * 4 + sel];
+        q += part[(r * nch + c) * 4 + sel + 1];
+      }
+    }
+    out[g * 2] = s;
+    out[g * 2 + 1] = q;
+  }
 }
 
 // pass 2: combine partials -> (mean, rstd) per (batch, group)
