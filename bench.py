@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 512x512 inpaint stamps/sec @ 20 DDIM steps (BASELINE.json `metric`).
+
+A "step" is one pass of the stamp path (canvas RGBA -> VAE-encode x2 -> 19 UNet evaluations with
+3-branch guidance -> VAE-decode -> RGB patch) over one batch of synthetic stamps per GPU, inputs
+resident in HBM.  N=1 runs BASELINE.json configs[1] (single 512x512 patch, 20 steps, fp16, latency
+mode); with N>1 every rank runs the same per-GPU workload on its own stamps (weak scaling) and the
+decoded u8 patches are gathered to rank 0 over RCCL inside the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--res R] [--ddim-steps S]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed inside this
+process) and `cpu_baseline` (the fp32 CPU oracle timed on a bounded sample, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(res, ddim_steps, weights, budget_note):
+    """fp32 CPU oracle (oracle/, kind "port") on a bounded sample of the same workload: one UNet
+    evaluation (batch 3), one VAE encode and one VAE decode at full resolution, extrapolated to the
+    stamp = (steps-1) UNet evals + 2 encodes + 1 decode."""
+    from oracle import nets
+    h = res // 8
+    g = torch.Generator().manual_seed(0)
+    unet = nets.merge_lora(weights["unet"], weights["lora"])
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        nets.unet_forward(unet, torch.randn(3, 9, h, h, generator=g), torch.tensor(501.0), torch.randn(3, 14, 768, generator=g))
+        t1 = time.perf_counter()
+        nets.vae_encode(weights["vae"], torch.rand(1, 3, res, res, generator=g) * 2 - 1, torch.randn(1, 4, h, h, generator=g))
+        t2 = time.perf_counter()
+        nets.vae_decode(weights["vae"], torch.randn(1, 4, h, h, generator=g))
+        t3 = time.perf_counter()
+    tu, te, td = t1 - t0, t2 - t1, t3 - t2
+    stamp_s = (ddim_steps - 1) * tu + 2 * te + td
+    return {"value": 1.0 / stamp_s, "unit": "stamps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 UNet eval (batch 3) {tu:.2f}s + 1 VAE encode {te:.2f}s + 1 VAE decode {td:.2f}s at {res}x{res}, "
+                      f"extrapolated to {ddim_steps - 1} evals + 2 encodes + 1 decode = {stamp_s:.1f}s/stamp; {budget_note}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10, help="timed stamp batches per rank")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1, help="stamps per GPU per step (1 = configs[1], 8 = configs[2])")
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--ddim-steps", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    a = ap.parse_args()
+
+    from diffusiontexturepainting_amd import dist as D, synthetic, weights as W
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+
+    rank, world, local = D.init_from_env("nccl")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    sd = dict(unet=W.synthetic_unet(), lora=W.synthetic_lora(), vae=W.synthetic_vae())
+    model = MI355ConditionalInpainter(a.res, device=local, weights=sd, max_batch=a.batch)
+    settings = dict(steps=a.ddim_steps, context_pad=150, tg_steps=a.ddim_steps, cfg_weight=2.0, tg_weight=1.0)  # Kit defaults
+    canvas, brush, lat, eps = synthetic.make_stamp_batch(a.batch, a.res, seed=1000 + rank)
+    cond, uncond = synthetic.make_conditioning(7)
+    model.set_conditioning(cond, uncond, brush)  # replicated on every rank
+    canvas, lat, eps = canvas.to(dev), lat.to(dev), eps.to(dev)
+    n_total = a.batch * world
+
+    def one_step():
+        out = model._stamp(canvas, settings, composite=True, latents=lat, vae_eps=eps, output_u8=True)
+        return D.gather_patches(out, n_total, rank, world)
+
+    for _ in range(a.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    lat_ms = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        s0 = time.perf_counter()
+        one_step()
+        torch.cuda.synchronize()
+        lat_ms.append((time.perf_counter() - s0) * 1e3)
+    D.barrier()
+    torch.cuda.synchronize()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    stage = model.stage_times_ms()
+    info = model.stamp_info()
+
+    roof = None
+    if not a.no_profile and rank == 0:
+        # one more pass of the same stamp with every launch bracketed by HIP events on its stream
+        model.profile(True)
+        one_step() if world == 1 else model._stamp(canvas, settings, composite=True, latents=lat, vae_eps=eps, output_u8=True)
+        rows = model.profile_rows()
+        model.profile(False)
+        tot_ms = sum(r["ms"] for r in rows)
+        dom = max(rows, key=lambda r: r["ms"])
+        gem = [r for r in rows if r["kernel"].startswith("gemm_kernel")]
+        roof = {
+            "bound": "mfma", "kernel": dom["kernel"],
+            "achieved": dom["flops"] / (dom["ms"] * 1e-3) / 1e12, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS,
+            "launches": dom["launches"], "avg_launch_us": dom["ms"] * 1e3 / dom["launches"],
+            "algorithmic_tflop_per_stamp_batch": dom["flops"] / 1e12, "traffic": None,
+            "all_gemm_tiles_achieved": sum(r["flops"] for r in gem) / (sum(r["ms"] for r in gem) * 1e-3) / 1e12,
+            "kernels": [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["ms"], 3),
+                         "share": round(r["ms"] / tot_ms, 4),
+                         "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1),
+                         "algo_GBps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in rows],
+        }
+    cpu = None
+    if not a.no_cpu_baseline and rank == 0 and world == 1:
+        cpu = cpu_baseline(a.res, a.ddim_steps, sd, "bounded sample, not a full stamp")
+
+    if rank == 0:
+        lat_sorted = sorted(lat_ms)
+        line = {
+            "metric": "512x512 inpaint stamps/sec @20 DDIM steps" if (a.res, a.ddim_steps) == (512, 20) else
+                      f"{a.res}x{a.res} inpaint stamps/sec @{a.ddim_steps} DDIM steps",
+            "value": n_total * a.steps / elapsed, "unit": "stamps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{1 if a.batch == 1 else 2}]: {a.batch} x {a.res}x{a.res} RGBA stamp(s) per GPU, "
+                                   f"{a.ddim_steps} DDIM steps = {a.ddim_steps - 1} UNet evals (reference quirk), 3 guidance branches, "
+                                   "cfg 2.0 / tg 1.0 / tg_steps = steps / context_pad 150, SD-1.5-inpaint UNet + LoRA merged + "
+                                   "AutoencoderKL with seeded synthetic weights, conditioning cached",
+                       "stamps_per_gpu_per_step": a.batch, "resolution": a.res, "ddim_steps": a.ddim_steps,
+                       "unet_evals": info["unet_evals"], "graph_nodes": info["graph_nodes"],
+                       "gather": "rccl gather of u8 patches to rank 0" if world > 1 else "none (1 GPU)"},
+            "p50_stamp_latency_ms": lat_sorted[len(lat_sorted) // 2], "p95_stamp_latency_ms": lat_sorted[int(len(lat_sorted) * 0.95)],
+            "stage_ms": {"pre+vae_encode_x2": stage[0], "denoise_loop": stage[1], "vae_decode+post": stage[2]},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,14 @@ class Settings(C.Structure):
                 ("tg_weight", C.c_float), ("composite", C.c_int), ("output_u8", C.c_int)]
 
 
+class ProfRow(C.Structure):
+    _fields_ = [("kind", C.c_int), ("launches", C.c_int), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+PROF_KINDS = ["gemm_kernel<128,128>", "gemm_kernel<128,64>", "gemm_kernel<64,64>", "gemm_kernel<64,128>", "attention_kernel",
+              "groupnorm(3 kernels)", "layernorm_kernel", "concat_kernel", "softmax_rows_kernel"]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
@@ -47,6 +55,9 @@ SYMBOLS = {
     "dtp_ddim_tables": (_i, [_i, C.POINTER(_i64), C.POINTER(_f), C.POINTER(_f)]),
     "dtp_last_stamp_times": (_i, [_vp, C.POINTER(_f * 3)]),
     "dtp_last_stamp_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "dtp_profile": (_i, [_vp, _i]),
+    "dtp_profile_rows": (_i, [_vp, C.POINTER(ProfRow), _i, C.POINTER(_i)]),
+    "dtp_set_option": (_i, [_vp, C.c_char_p, _i]),
     "dtp_op_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "dtp_op_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dtp_op_pack_conv": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

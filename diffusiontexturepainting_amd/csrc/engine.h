@@ -25,7 +25,7 @@ struct Staged {
 struct ConvW {  // 3x3 (taps = 9) or 1x1 (taps = 1) convolution / any Linear (taps = 1)
   f16* w = nullptr;
   float* b = nullptr;  // fp32 bias (may be null)
-  int cout = 0, cin = 0 /* padded */, taps = 1, K = 0, ldw = 0;
+  int cout = 0, cin = 0 /* padded */, cin_true = 0, taps = 1, K = 0, ldw = 0;
 };
 struct NormW {
   float *g = nullptr, *b = nullptr;
@@ -43,6 +43,13 @@ struct Ctx;
 
 // A launch program: a flat list of closures bound to statically planned buffers.
 using Op = std::function<int(hipStream_t, int /*step*/)>;
+// profiling classes (dtp_profile_rows): 0-3 = gemm_kernel tile variants, then the HBM-bound kernels
+enum { PK_GEMM0 = 0, PK_ATTN = 4, PK_GN = 5, PK_LN = 6, PK_ELEM = 7, PK_SOFTMAX = 8, PK_COUNT = 9 };
+struct ProfRec {
+  int kind;
+  double flops, bytes;
+  hipEvent_t e0, e1;
+};
 struct Prog {
   std::vector<Op> ops;
   int run(hipStream_t s, int step) const {
@@ -187,6 +194,8 @@ struct Ctx {
   int last_evals = 0, last_nodes = 0;
   bool use_graph = true;
   bool exec_imgenc_ready = false;
+  bool profile = false;
+  std::vector<ProfRec> prof;
 };
 
 // ---- engine.hip
@@ -208,6 +217,8 @@ int load_plain_f16(Ctx* c, const std::string& name, f16** out);  // unpadded fp1
 struct Builder {
   Ctx* c;
   Prog* prog;
+  // append an op; when profiling is on, every launch is bracketed by HIP events on its own stream
+  void push(int kind, double flops, double bytes, Op fn);
   T alloc(int B, int H, int W, int C);
   void release(const T& t);
   int gn(const T& x, const NormW& n, float eps, bool silu, T& y);

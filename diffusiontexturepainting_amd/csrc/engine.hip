@@ -105,7 +105,7 @@ int load_conv(Ctx* c, const std::string& name, ConvW& w, int cin_pad, bool bias)
   const int cout = (int)s->shape[0], cin = (int)s->shape[1];
   const int taps = s->shape.size() == 4 ? (int)(s->shape[2] * s->shape[3]) : 1;
   if (cin_pad <= 0) cin_pad = (int)up_to(cin, 8);
-  w.cout = cout; w.cin = cin_pad; w.taps = taps; w.K = taps * cin_pad; w.ldw = (int)up_to(w.K, 64);
+  w.cout = cout; w.cin = cin_pad; w.cin_true = cin; w.taps = taps; w.K = taps * cin_pad; w.ldw = (int)up_to(w.K, 64);
   void* p;
   RC(ctx_arena_alloc(c, up_to(cout, 128) * (size_t)w.ldw * 2, &p));
   w.w = (f16*)p;
@@ -132,7 +132,7 @@ int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bi
     K = k;
     N += (int)s->shape[0];
   }
-  w.cout = N; w.cin = K; w.taps = 1; w.K = K; w.ldw = (int)up_to(K, 64);
+  w.cout = N; w.cin = K; w.cin_true = K; w.taps = 1; w.K = K; w.ldw = (int)up_to(K, 64);
   void* p;
   RC(ctx_arena_alloc(c, up_to(N, 128) * (size_t)w.ldw * 2, &p));
   w.w = (f16*)p;
@@ -203,6 +203,22 @@ int ensure_ws(Ctx* c) {
 }
 
 // ---------------------------------------------------------------- builder
+void prog_push(Ctx* c, Prog* prog, int kind, double flops, double bytes, Op fn) {
+  prog->ops.push_back([=](hipStream_t s, int step) -> int {
+    if (!c->profile) return fn(s, step);
+    ProfRec r;
+    r.kind = kind; r.flops = flops; r.bytes = bytes;
+    HIP_CHECK(hipEventCreate(&r.e0));
+    HIP_CHECK(hipEventCreate(&r.e1));
+    HIP_CHECK(hipEventRecord(r.e0, s));
+    const int rc = fn(s, step);
+    HIP_CHECK(hipEventRecord(r.e1, s));
+    c->prof.push_back(r);
+    return rc;
+  });
+}
+void Builder::push(int kind, double flops, double bytes, Op fn) { prog_push(c, prog, kind, flops, bytes, fn); }
+
 T Builder::alloc(int B, int H, int W, int C) {
   T t;
   t.B = B; t.H = H; t.W = W; t.C = C; t.ld = C;
@@ -220,7 +236,7 @@ int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
   cc->ws_need = std::max(cc->ws_need, dtp_groupnorm_ws_bytes(x.B, x.H * x.W, x.C, 32));
   const T xx = x, yy = y;
   const NormW nn = n;
-  prog->ops.push_back([=](hipStream_t s, int) {
+  push(PK_GN, 0.0, 4.0 * (double)xx.rows() * xx.C, [=](hipStream_t s, int) {
     return dtp_launch_groupnorm(xx.p, xx.ld, yy.p, yy.ld, nn.g, nn.b, cc->ws, xx.B, xx.H * xx.W, xx.C, 32, eps, silu ? 1 : 0, s);
   });
   return DTP_OK;
@@ -231,18 +247,24 @@ int Builder::ln(const T& x, const NormW& n, T& y) {
   if (!y.p) return DTP_ERR_HIP;
   const T xx = x, yy = y;
   const NormW nn = n;
-  prog->ops.push_back([=](hipStream_t s, int) {
+  push(PK_LN, 0.0, 4.0 * (double)xx.rows() * xx.C, [=](hipStream_t s, int) {
     return dtp_launch_layernorm(xx.p, xx.ld, yy.p, yy.ld, nn.g, nn.b, (int)xx.rows(), xx.C, 1e-5f, s);
   });
   return DTP_OK;
 }
 
-static int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off) {
+void prog_push(Ctx* c, Prog* prog, int kind, double flops, double bytes, Op fn);
+int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg) {
   int tile = 0;
   dtp_gemm_pick(p, &tile, c->num_cu);
   c->ws_need = std::max(c->ws_need, dtp_gemm_workspace_bytes(p));
   p.zero = c->zero;
-  prog->ops.push_back([=](hipStream_t s, int step) {
+  // algorithmic work: 2*M*N*K on the UNPADDED contraction; bytes = A once + W once + C once (fp16)
+  const double n_out = (p.flags & GF_GEGLU) ? p.N / 2.0 : (double)p.N;
+  const double a_elems = (p.flags & GF_CONV3) ? (double)p.M * (k_alg / 9.0) * ((p.flags & GF_UPS2) ? 0.25 : (double)(p.stride * p.stride))
+                                               : (double)p.M * k_alg;
+  const double bytes = 2.0 * (a_elems + (double)p.N * k_alg + (double)p.M * n_out);
+  prog_push(c, prog, PK_GEMM0 + tile, 2.0 * p.M * (double)p.N * k_alg, bytes, [=](hipStream_t s, int step) {
     GemmParams q = p;
     q.part = c->ws;
     if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;
@@ -271,7 +293,7 @@ int Builder::conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, in
   p.C = y.p; p.ldc = y.ld;
   if (w.b || bias_step_off >= 0) { p.flags |= GF_BIAS; p.bias = w.b; }
   if (resid) { p.flags |= GF_RESID; p.R = resid->p; p.ldr = resid->ld; }
-  return push_gemm(c, prog, p, bias_step_off);
+  return push_gemm(c, prog, p, bias_step_off, 9.0 * w.cin_true);
 }
 
 int Builder::linear(const T& x, const ConvW& w, const T* resid, int flags, T& y) {
@@ -286,7 +308,7 @@ int Builder::linear(const T& x, const ConvW& w, const T* resid, int flags, T& y)
   p.C = y.p; p.ldc = y.ld;
   if (w.b) { p.flags |= GF_BIAS; p.bias = w.b; }
   if (resid) { p.flags |= GF_RESID; p.R = resid->p; p.ldr = resid->ld; }
-  return push_gemm(c, prog, p, -1);
+  return push_gemm(c, prog, p, -1, (double)w.K);
 }
 
 int Builder::attention(const T& q, const T& k, const T& v, int heads, int Sq, int Skv, int Bn, T& o) {
@@ -298,7 +320,8 @@ int Builder::attention(const T& q, const T& k, const T& v, int heads, int Sq, in
   a.B = Bn; a.H = heads; a.Sq = Sq; a.Skv = Skv; a.D = q.C / heads;
   a.qbs = (long long)Sq * q.ld; a.kbs = (long long)Skv * k.ld; a.vbs = (long long)Skv * v.ld; a.obs = (long long)Sq * o.ld;
   a.scale = 1.0f / sqrtf((float)a.D);
-  prog->ops.push_back([=](hipStream_t s, int) { return dtp_launch_attention(a, s); });
+  push(PK_ATTN, 4.0 * Bn * heads * (double)Sq * Skv * a.D, 2.0 * Bn * q.C * (2.0 * Sq + 2.0 * Skv),
+       [=](hipStream_t s, int) { return dtp_launch_attention(a, s); });
   return DTP_OK;
 }
 
@@ -306,7 +329,7 @@ int Builder::concat(const T& a, const T& b, T& y) {
   y = alloc(a.B, a.H, a.W, a.C + b.C);
   if (!y.p) return DTP_ERR_HIP;
   const T aa = a, bb = b, yy = y;
-  prog->ops.push_back([=](hipStream_t s, int) {
+  push(PK_ELEM, 0.0, 4.0 * (double)aa.rows() * (aa.C + bb.C), [=](hipStream_t s, int) {
     return dtp_launch_concat_channels(aa.p, aa.ld, aa.C, bb.p, bb.ld, bb.C, yy.p, yy.ld, aa.rows(), s);
   });
   return DTP_OK;

@@ -3,6 +3,7 @@
 // Reference: trt_inference/trt_model.py:90-121, handler.py:25-33,55-56, model_base.py:51-58,
 // inpaint_pipeline.py:39-153, stable_diffusion_pipeline.py:340-355,407-484, utilities.py:370-529.
 #include <math.h>
+#include <string.h>
 
 #include "engine.h"
 
@@ -240,7 +241,7 @@ static int get_bufs(Ctx* c, int B, StampBufs** out) {
 // run `body` on stream s, replaying a captured hipGraph when possible
 template <class F>
 static int run_stage(Ctx* c, long long key, hipStream_t s, F body) {
-  if (!c->use_graph || s == nullptr) return body(s);
+  if (!c->use_graph || c->profile || s == nullptr) return body(s);
   auto it = c->graphs.find(key);
   if (it == c->graphs.end()) {
     StampGraph g;
@@ -423,6 +424,43 @@ int dtp_last_stamp_times(dtp_ctx* ctx, float ms[3]) {
   HIP_CHECK(hipEventSynchronize(c->ev[3]));
   for (int i = 0; i < 3; ++i) HIP_CHECK(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
   return DTP_OK;
+}
+
+int dtp_profile(dtp_ctx* ctx, int enable) {
+  Ctx* c = (Ctx*)ctx;
+  if (!c) return DTP_ERR_ARG;
+  HIP_CHECK(hipDeviceSynchronize());
+  for (ProfRec& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  c->prof.clear();
+  c->profile = enable != 0;
+  return DTP_OK;
+}
+
+int dtp_profile_rows(dtp_ctx* ctx, dtp_prof_row* rows, int max_rows, int* n_rows) {
+  Ctx* c = (Ctx*)ctx;
+  if (!c || !rows || !n_rows) return DTP_ERR_ARG;
+  HIP_CHECK(hipDeviceSynchronize());
+  dtp_prof_row acc[PK_COUNT] = {};
+  for (int k = 0; k < PK_COUNT; ++k) acc[k].kind = k;
+  for (const ProfRec& r : c->prof) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+    dtp_prof_row& a = acc[r.kind];
+    a.launches += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+  }
+  int n = 0;
+  for (int k = 0; k < PK_COUNT && n < max_rows; ++k)
+    if (acc[k].launches) rows[n++] = acc[k];
+  *n_rows = n;
+  return DTP_OK;
+}
+
+int dtp_set_option(dtp_ctx* ctx, const char* name, int value) {
+  Ctx* c = (Ctx*)ctx;
+  if (!c || !name) return DTP_ERR_ARG;
+  if (!strcmp(name, "use_graph")) { c->use_graph = value != 0; return DTP_OK; }
+  dtp_set_error("dtp_set_option: unknown option '%s'", name);
+  return DTP_ERR_ARG;
 }
 
 int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes) {

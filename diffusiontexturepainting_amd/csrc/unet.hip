@@ -218,7 +218,8 @@ int build_unet_prog(Ctx* c, int N, UNetProg& up) {
       g.M = N * 14; g.N = w->kv2.cout; g.K = 768; g.lda = 768; g.ldw = w->kv2.ldw; g.ldc = w->kv2.cout; g.nkb = w->kv2.ldw / 64;
       g.zero = c->zero;
       g.splits = 1; g.kb_per_split = g.nkb;
-      up.kv.ops.push_back([=](hipStream_t s, int) { return dtp_launch_gemm(g, 3, s); });
+      b.push(PK_GEMM0 + 3, 2.0 * g.M * (double)g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N),
+             [=](hipStream_t s, int) { return dtp_launch_gemm(g, 3, s); });
     }
   }
   // ---- main program

@@ -80,7 +80,8 @@ static int vae_attention(Builder& b, const T& x, const VaeAttnW& w, T& out) {
       g.nkb = (g.K + 63) / 64;
       dtp_gemm_pick(g, &tile, c->num_cu);
       g.splits = 1; g.kb_per_split = g.nkb;
-      b.prog->ops.push_back([=](hipStream_t s, int) { return dtp_launch_gemm(g, tile, s); });
+      b.push(PK_GEMM0 + tile, 2.0 * g.M * (double)g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N),
+             [=](hipStream_t s, int) { return dtp_launch_gemm(g, tile, s); });
     };
     GemmParams g = {};
     // V^T[c][s] = Wv[c][:] . t[s][:] + bv[c]
@@ -93,7 +94,7 @@ static int vae_attention(Builder& b, const T& x, const VaeAttnW& w, T& out) {
     g.M = S; g.N = S; g.K = C; g.lda = qk.ld; g.ldw = qk.ld; g.ldc = S;
     push(g);
     const T scc = sc;
-    b.prog->ops.push_back([=](hipStream_t s, int) { return dtp_launch_softmax_rows(scc.p, S, scc.p, S, S, S, scale, s); });
+    b.push(PK_SOFTMAX, 0.0, 4.0 * (double)S * S, [=](hipStream_t s, int) { return dtp_launch_softmax_rows(scc.p, S, scc.p, S, S, S, scale, s); });
     // O[q][c] = P[q][:] . V^T[c][:]
     g = GemmParams();
     g.A = sc.p; g.W = vt.p; g.C = o.p + (size_t)bi * S * o.ld;

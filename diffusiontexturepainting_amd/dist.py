@@ -1,0 +1,69 @@
+"""Stamp-level data parallelism: independent stamps are sharded across
+the GPUs of a node -- one process per GPU, full model replica each -- and the decoded patches
+are gathered to rank 0 with ONE collective (RCCL gather over xGMI; rank 0 has a direct link to
+every peer, so the flat gather is 7 concurrent point-to-point transfers).  There is no other
+data-path collective: stamps do not interact.  The reference has no multi-GPU path at all.
+
+`backend="nccl"` is RCCL on ROCm; the same code runs on `gloo` for the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [lo, hi) of `n_items` stamps for `rank`; the first n_items % world ranks
+    get one extra stamp (ragged batches are allowed)."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_patches(local, n_total, rank, world, dst=0):
+    """Gather per-rank patch tensors [b_r, ...] to `dst` in stamp order -> [n_total, ...] on dst, None
+    elsewhere.  Shards may be ragged; every rank pads to the largest shard so the collective is a
+    single fixed-size gather."""
+    if world == 1:
+        return local
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    counts = [hi - lo for lo, hi in sizes]
+    mx = max(counts)
+    if local.shape[0] < mx:
+        pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], dim=0)
+    local = local.contiguous()
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    dist.gather(local, gather_list=bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:n] for b, n in zip(bufs, counts)], dim=0)
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -159,6 +159,20 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
         check(self._lib.dtp_last_stamp_info(self._h, C.byref(a), C.byref(b)), "dtp_last_stamp_info")
         return dict(unet_evals=a.value, graph_nodes=b.value)
 
+    def profile(self, enable):
+        """Bracket every kernel launch with HIP events (graph replay off) / switch back."""
+        check(self._lib.dtp_profile(self._h, int(enable)), "dtp_profile")
+
+    def profile_rows(self):
+        rows = (_lib.ProfRow * 16)()
+        n = C.c_int()
+        check(self._lib.dtp_profile_rows(self._h, rows, 16, C.byref(n)), "dtp_profile_rows")
+        return [dict(kernel=_lib.PROF_KINDS[r.kind], launches=r.launches, ms=r.ms, flops=r.flops, bytes=r.bytes)
+                for r in rows[: n.value]]
+
+    def set_option(self, name, value):
+        check(self._lib.dtp_set_option(self._h, name.encode(), int(value)), "dtp_set_option")
+
     # ------------------------------------------------------------------ engine-level access (inner boundary)
     def unet(self, sample, timestep, encoder_hidden_states):
         """Engine contract of models.py:1097-1129: sample f32 [N,9,h,w], timestep scalar, ehs f16 [N,14,768]."""

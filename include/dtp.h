@@ -101,6 +101,20 @@ int dtp_last_stamp_times(dtp_ctx* ctx, float ms[3]);
 /* number of UNet evaluations / kernel launches captured for the last stamp */
 int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes);
 
+/* ---------------------------------------------------------------- measurement
+ * dtp_profile(ctx, 1): from now on every kernel launch of the engines is bracketed by HIP events on
+ * the stream it runs on (graph replay is bypassed); dtp_profile_rows() aggregates them per kernel
+ * class: kind 0-3 = gemm_kernel<128,128>/<128,64>/<64,64>/<64,128> (the implicit-GEMM kernel),
+ * 4 = attention_kernel, 5 = GroupNorm (3 kernels), 6 = layernorm, 7 = concat/elementwise,
+ * 8 = softmax_rows.  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
+ * dtp_profile(ctx, 0) switches back to graph replay.  The nvtx/cudaEvent hooks of
+ * stable_diffusion_pipeline.py:146-149,486-503 are the reference counterpart. */
+typedef struct { int kind; int launches; double ms; double flops; double bytes; } dtp_prof_row;
+int dtp_profile(dtp_ctx* ctx, int enable);
+int dtp_profile_rows(dtp_ctx* ctx, dtp_prof_row* rows, int max_rows, int* n_rows);
+/* options: "use_graph" (default 1) */
+int dtp_set_option(dtp_ctx* ctx, const char* name, int value);
+
 /* ---------------------------------------------------------------- kernel-level entry points
  * The individual HIP kernels behind the engines, exposed so each can
  * be parity-tested and profiled on its own.  All pointers are device memory; fp16 activations
