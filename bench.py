@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dump-launches", default="", help="CSV with one line per profiled kernel launch")
     a = ap.parse_args()
 
     from diffusiontexturepainting_amd import dist as D, synthetic, weights as W
@@ -109,6 +110,8 @@ def main():
         model.profile(True)
         one_step() if world == 1 else model._stamp(canvas, settings, composite=True, latents=lat, vae_eps=eps, output_u8=True)
         rows = model.profile_rows()
+        if a.dump_launches:
+            model.profile_dump(a.dump_launches)
         model.profile(False)
         tot_ms = sum(r["ms"] for r in rows)
         dom = max(rows, key=lambda r: r["ms"])

@@ -3,6 +3,8 @@ missing or an entry point fails, the caller gets an exception."""
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must come first: libdtp.so has to bind to the HIP runtime torch already loaded
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdtp.so")
 _lib = None
@@ -57,6 +59,7 @@ SYMBOLS = {
     "dtp_last_stamp_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "dtp_profile": (_i, [_vp, _i]),
     "dtp_profile_rows": (_i, [_vp, C.POINTER(ProfRow), _i, C.POINTER(_i)]),
+    "dtp_profile_dump": (_i, [_vp, C.c_char_p]),
     "dtp_set_option": (_i, [_vp, C.c_char_p, _i]),
     "dtp_op_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "dtp_op_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -49,6 +49,7 @@ struct ProfRec {
   int kind;
   double flops, bytes;
   hipEvent_t e0, e1;
+  const char* label;  // owned by the closure's std::string (lives as long as the program)
 };
 struct Prog {
   std::vector<Op> ops;
@@ -196,6 +197,11 @@ struct Ctx {
   bool exec_imgenc_ready = false;
   bool profile = false;
   std::vector<ProfRec> prof;
+  bool autotune = true;            // time every (tile, split-K) candidate of each distinct GEMM shape at build time
+  std::map<std::string, std::pair<int, int>> tuned;  // shape key -> (tile, splits)
+  hipEvent_t tune_ev[2] = {nullptr, nullptr};
+  std::string tune_cache_path;     // $DTP_TUNE_CACHE: persisted (shape -> tile, splits) table
+  size_t tune_saved = 0;
 };
 
 // ---- engine.hip
@@ -218,7 +224,7 @@ struct Builder {
   Ctx* c;
   Prog* prog;
   // append an op; when profiling is on, every launch is bracketed by HIP events on its own stream
-  void push(int kind, double flops, double bytes, Op fn);
+  void push(int kind, double flops, double bytes, Op fn, const std::string& label = std::string());
   T alloc(int B, int H, int W, int C);
   void release(const T& t);
   int gn(const T& x, const NormW& n, float eps, bool silu, T& y);
@@ -238,6 +244,8 @@ int build_vae_dec_prog(Ctx* c, int B, VaeDecProg& p);
 int load_unet_weights(Ctx* c);
 int load_vae_weights(Ctx* c);
 int ensure_ws(Ctx* c);
+void tune_cache_load(Ctx* c);
+void tune_cache_save(Ctx* c);
 int ensure_temb(Ctx* c, const std::vector<float>& timesteps);  // fills temb_table rows 0..n-1
 
 // ---- stamp.hip

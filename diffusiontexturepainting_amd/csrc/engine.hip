@@ -2,6 +2,8 @@
 #include "engine.h"
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -203,11 +205,11 @@ int ensure_ws(Ctx* c) {
 }
 
 // ---------------------------------------------------------------- builder
-void prog_push(Ctx* c, Prog* prog, int kind, double flops, double bytes, Op fn) {
+void prog_push(Ctx* c, Prog* prog, int kind, double flops, double bytes, Op fn, const std::string& label) {
   prog->ops.push_back([=](hipStream_t s, int step) -> int {
     if (!c->profile) return fn(s, step);
     ProfRec r;
-    r.kind = kind; r.flops = flops; r.bytes = bytes;
+    r.kind = kind; r.flops = flops; r.bytes = bytes; r.label = label.c_str();
     HIP_CHECK(hipEventCreate(&r.e0));
     HIP_CHECK(hipEventCreate(&r.e1));
     HIP_CHECK(hipEventRecord(r.e0, s));
@@ -217,7 +219,7 @@ void prog_push(Ctx* c, Prog* prog, int kind, double flops, double bytes, Op fn) 
     return rc;
   });
 }
-void Builder::push(int kind, double flops, double bytes, Op fn) { prog_push(c, prog, kind, flops, bytes, fn); }
+void Builder::push(int kind, double flops, double bytes, Op fn, const std::string& label) { prog_push(c, prog, kind, flops, bytes, fn, label); }
 
 T Builder::alloc(int B, int H, int W, int C) {
   T t;
@@ -238,7 +240,7 @@ int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
   const NormW nn = n;
   push(PK_GN, 0.0, 4.0 * (double)xx.rows() * xx.C, [=](hipStream_t s, int) {
     return dtp_launch_groupnorm(xx.p, xx.ld, yy.p, yy.ld, nn.g, nn.b, cc->ws, xx.B, xx.H * xx.W, xx.C, 32, eps, silu ? 1 : 0, s);
-  });
+  }, "gn B=" + std::to_string(x.B) + " HW=" + std::to_string(x.H * x.W) + " C=" + std::to_string(x.C));
   return DTP_OK;
 }
 
@@ -253,10 +255,78 @@ int Builder::ln(const T& x, const NormW& n, T& y) {
   return DTP_OK;
 }
 
-void prog_push(Ctx* c, Prog* prog, int kind, double flops, double bytes, Op fn);
+void prog_push(Ctx* c, Prog* prog, int kind, double flops, double bytes, Op fn, const std::string& label);
+void tune_cache_load(Ctx* c) {
+  const char* e = getenv("DTP_TUNE_CACHE");
+  if (!e || !*e) return;
+  c->tune_cache_path = e;
+  FILE* f = fopen(e, "r");
+  if (!f) return;
+  char key[256];
+  int tile, splits;
+  while (fscanf(f, "%255s %d %d", key, &tile, &splits) == 3) c->tuned[key] = std::make_pair(tile, splits);
+  fclose(f);
+  c->tune_saved = c->tuned.size();
+}
+
+void tune_cache_save(Ctx* c) {
+  if (c->tune_cache_path.empty() || c->tuned.size() == c->tune_saved) return;
+  FILE* f = fopen(c->tune_cache_path.c_str(), "w");
+  if (!f) return;
+  for (auto& kv : c->tuned) fprintf(f, "%s %d %d\n", kv.first.c_str(), kv.second.first, kv.second.second);
+  fclose(f);
+  c->tune_saved = c->tuned.size();
+}
+
+// Build-time autotuning: the stamp path has ~100 distinct contraction shapes, most of them far from
+// "large square GEMM" (M from 192 to 524288, N from 3 to 10240).  Each distinct shape is timed once
+// with every tile variant x split-K factor on the real buffers and the fastest pair is kept.
+static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
+  char key[200];
+  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin, p.stride,
+           p.lda, p.ldc, p.ldw);
+  auto it = c->tuned.find(key);
+  if (it == c->tuned.end()) {
+    if (!c->tune_ev[0]) { HIP_CHECK(hipEventCreate(&c->tune_ev[0])); HIP_CHECK(hipEventCreate(&c->tune_ev[1])); }
+    float best = 1e30f;
+    int bt = *tile_out, bs = p.splits;
+    const bool geglu = (p.flags & GF_GEGLU) != 0;
+    static const int cand_splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+    for (int tile = 0; tile < 4; ++tile) {
+      if (geglu && !(tile == 0 || tile == 3)) continue;
+      for (int sp : cand_splits) {
+        if (sp > 1 && (geglu || p.nkb / sp < 2)) break;
+        GemmParams q = p;
+        q.kb_per_split = (p.nkb + sp - 1) / sp;
+        q.splits = (p.nkb + q.kb_per_split - 1) / q.kb_per_split;
+        if (q.splits != sp && sp > 1) continue;
+        const size_t need = dtp_gemm_workspace_bytes(q);
+        if (need > ((size_t)512 << 20)) continue;
+        if (need > c->ws_bytes) { c->ws_need = std::max(c->ws_need, need); RC(ensure_ws(c)); }
+        q.part = c->ws;
+        q.zero = c->zero;
+        for (int i = 0; i < 2; ++i) RC(dtp_launch_gemm(q, tile, 0));
+        HIP_CHECK(hipEventRecord(c->tune_ev[0], 0));
+        for (int i = 0; i < 4; ++i) RC(dtp_launch_gemm(q, tile, 0));
+        HIP_CHECK(hipEventRecord(c->tune_ev[1], 0));
+        HIP_CHECK(hipEventSynchronize(c->tune_ev[1]));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, c->tune_ev[0], c->tune_ev[1]));
+        if (ms < best) { best = ms; bt = tile; bs = sp; }
+      }
+    }
+    it = c->tuned.emplace(key, std::make_pair(bt, bs)).first;
+  }
+  *tile_out = it->second.first;
+  p.kb_per_split = (p.nkb + it->second.second - 1) / it->second.second;
+  p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
+  return DTP_OK;
+}
+
 int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg) {
   int tile = 0;
   dtp_gemm_pick(p, &tile, c->num_cu);
+  if (c->autotune) RC(tune_gemm(c, p, &tile));
   c->ws_need = std::max(c->ws_need, dtp_gemm_workspace_bytes(p));
   p.zero = c->zero;
   // algorithmic work: 2*M*N*K on the UNPADDED contraction; bytes = A once + W once + C once (fp16)
@@ -264,12 +334,15 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg)
   const double a_elems = (p.flags & GF_CONV3) ? (double)p.M * (k_alg / 9.0) * ((p.flags & GF_UPS2) ? 0.25 : (double)(p.stride * p.stride))
                                                : (double)p.M * k_alg;
   const double bytes = 2.0 * (a_elems + (double)p.N * k_alg + (double)p.M * n_out);
+  char lab[160];
+  snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
+           p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? " geglu" : "", p.stride == 2 ? " s2" : "");
   prog_push(c, prog, PK_GEMM0 + tile, 2.0 * p.M * (double)p.N * k_alg, bytes, [=](hipStream_t s, int step) {
     GemmParams q = p;
     q.part = c->ws;
     if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;
     return dtp_launch_gemm(q, tile, s);
-  });
+  }, lab);
   return DTP_OK;
 }
 
@@ -321,7 +394,8 @@ int Builder::attention(const T& q, const T& k, const T& v, int heads, int Sq, in
   a.qbs = (long long)Sq * q.ld; a.kbs = (long long)Skv * k.ld; a.vbs = (long long)Skv * v.ld; a.obs = (long long)Sq * o.ld;
   a.scale = 1.0f / sqrtf((float)a.D);
   push(PK_ATTN, 4.0 * Bn * heads * (double)Sq * Skv * a.D, 2.0 * Bn * q.C * (2.0 * Sq + 2.0 * Skv),
-       [=](hipStream_t s, int) { return dtp_launch_attention(a, s); });
+       [=](hipStream_t s, int) { return dtp_launch_attention(a, s); },
+       "attn B=" + std::to_string(Bn) + " Sq=" + std::to_string(Sq) + " Skv=" + std::to_string(Skv) + " D=" + std::to_string(a.D));
   return DTP_OK;
 }
 
@@ -372,6 +446,7 @@ int dtp_create(int device, int resolution, int max_batch, dtp_ctx** out) {
   HIP_CHECK(hipMemset(z, 0, 4096));
   c->zero = (f16*)z;
   for (int i = 0; i < 4; ++i) HIP_CHECK(hipEventCreate(&c->ev[i]));
+  tune_cache_load(c);
   *out = (dtp_ctx*)c;
   return DTP_OK;
 }

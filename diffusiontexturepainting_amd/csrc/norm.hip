@@ -1,6 +1,7 @@
 // HBM-bound normalisation kernels for gfx950 (softmax of K14).
 // NHWC fp16 tensors, 16-byte (8 x f16) vector accesses, fp32 statistics, wave64 shuffles.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -60,45 +61,143 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int ldx, float* __res
   }
 }
 
-// pass 2: combine partials -> (mean, rstd) per (batch, group)
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nchunk, int groups,
-                                   float inv_count, float eps) {
-  const int b = blockIdx.x;
-  for (int g = threadIdx.x; g < groups; g += blockDim.x) {
-    float s = 0.f, q = 0.f;
-    for (int c = 0; c < nchunk; ++c) {
-      const float* p = partial + ((size_t)b * nchunk + c) * groups * 2 + g * 2;
-      s += p[0];
-      q += p[1];
-    }
-    const float mean = s * inv_count;
-    const float var = fmaxf(q * inv_count - mean * mean, 0.f);
-    stats[((size_t)b * groups + g) * 2] = mean;
-    stats[((size_t)b * groups + g) * 2 + 1] = rsqrtf(var + eps);
-  }
-}
-
-// pass 3: normalise (+ SiLU), elementwise over 8-channel chunks
+// pass 2: every block first combines the per-chunk partials of its batch item into (mean, rstd) for all
+// groups (8 lanes per group, fixed order -> deterministic), then normalises (+ SiLU) 8-channel chunks.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const float* __restrict__ stats, int HW, int C, int cpg, int groups,
-                                                        int silu, long long total_chunks) {
+                                                        const float* __restrict__ partial, int nchunk, int HW, int C, int cpg,
+                                                        int groups, int silu, float inv_count, float eps) {
+  __shared__ float st[64 * 2];
+  const int b = blockIdx.y;
+  {
+    const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
+    float s = 0.f, q = 0.f;
+    if (g < groups) {
+      const float* p = partial + (size_t)b * nchunk * groups * 2 + g * 2;
+      for (int c = j; c < nchunk; c += 8) { s += p[(size_t)c * groups * 2]; q += p[(size_t)c * groups * 2 + 1]; }
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (g < groups && j == 0) {
+      const float mean = s * inv_count;
+      const float var = fmaxf(q * inv_count - mean * mean, 0.f);
+      st[g * 2] = mean;
+      st[g * 2 + 1] = rsqrtf(var + eps);
+    }
+    if (groups > 32) {  // second half of the groups (not used on this path, kept for generality)
+      const int g2 = g + 32;
+      float s2 = 0.f, q2 = 0.f;
+      if (g2 < groups) {
+        const float* p = partial + (size_t)b * nchunk * groups * 2 + g2 * 2;
+        for (int c = j; c < nchunk; c += 8) { s2 += p[(size_t)c * groups * 2]; q2 += p[(size_t)c * groups * 2 + 1]; }
+      }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) { s2 += __shfl_xor(s2, o); q2 += __shfl_xor(q2, o); }
+      if (g2 < groups && j == 0) {
+        const float mean = s2 * inv_count;
+        st[g2 * 2] = mean;
+        st[g2 * 2 + 1] = rsqrtf(fmaxf(q2 * inv_count - mean * mean, 0.f) + eps);
+      }
+    }
+  }
+  __syncthreads();
   const int nch = C >> 3;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += (long long)gridDim.x * 256) {
+  const long long total = (long long)HW * nch;
+  const f16* xb = x + (size_t)b * HW * ldx;
+  f16* yb = y + (size_t)b * HW * ldy;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long pix = i / nch;
-    const int cc = (int)(i - pix * nch), c0 = cc * 8;
-    const int b = (int)(pix / HW);
-    const f16x8 v = *(const f16x8*)(x + (size_t)pix * ldx + c0);
-    const float* st = stats + (size_t)b * groups * 2;
+    const int c0 = (int)(i - pix * nch) * 8;
+    const f16x8 v = *(const f16x8*)(xb + (size_t)pix * ldx + c0);
+    const f32x4 ga = *(const f32x4*)(gamma + c0), gb = *(const f32x4*)(gamma + c0 + 4);
+    const f32x4 ba = *(const f32x4*)(beta + c0), bb = *(const f32x4*)(beta + c0 + 4);
+    const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
+    const float m0 = st[g0 * 2], r0 = st[g0 * 2 + 1];
+    const float m1 = st[(g0 + 1 < groups ? g0 + 1 : g0) * 2], r1 = st[(g0 + 1 < groups ? g0 + 1 : g0) * 2 + 1];
     f16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = c0 + e, g = c / cpg;
-      float f = ((float)v[e] - st[g * 2]) * st[g * 2 + 1] * gamma[c] + beta[c];
+      const float gm = e < 4 ? ga[e] : gb[e - 4], bt = e < 4 ? ba[e] : bb[e - 4];
+      const bool first = e < split;
+      float f = ((float)v[e] - (first ? m0 : m1)) * (first ? r0 : r1) * gm + bt;
       if (silu) f = f / (1.0f + __expf(-f));
       o[e] = (f16)f;
     }
-    *(f16x8*)(y + (size_t)pix * ldy + c0) = o;
+    *(f16x8*)(yb + (size_t)pix * ldy + c0) = o;
+  }
+}
+
+// Single-launch GroupNorm for small feature maps (HW <= 256: UNet levels 2-3, where the two-pass
+// version is pure launch latency).  One block per (batch, slab of G groups); the slab's channel range
+// is a whole number of 16-byte chunks.  Pass 1 accumulates per-group sums in registers (fixed-order
+// wave + LDS reduction, deterministic), pass 2 re-reads the slab (L2 resident) and normalises.
+template <int G>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int HW,
+                                                        int cpg, int silu, float inv_count, float eps) {
+  __shared__ float red[4][2 * G];
+  __shared__ float st[2 * G];
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int cs = slab * G * cpg;          // first channel of the slab
+  const int nchs = (G * cpg) >> 3;        // 16-byte chunks per pixel inside the slab
+  const f16* xb = x + (size_t)b * HW * ldx + cs;
+  f16* yb = y + (size_t)b * HW * ldy + cs;
+  float s[G], q[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) s[g] = q[g] = 0.f;
+  const int total = HW * nchs;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int pix = i / nchs, c0 = (i - pix * nchs) * 8;
+    const f16x8 v = *(const f16x8*)(xb + (size_t)pix * ldx + c0);
+    const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
+    float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = (float)v[e];
+      if (e < split) { a0 += f; b0 += f * f; } else { a1 += f; b1 += f * f; }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g == g0) { s[g] += a0; q[g] += b0; }
+      if (g == g0 + 1) { s[g] += a1; q[g] += b1; }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    s[g] = wave_sum(s[g]);
+    q[g] = wave_sum(q[g]);
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) { red[threadIdx.x >> 6][2 * g] = s[g]; red[threadIdx.x >> 6][2 * g + 1] = q[g]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    const int g = threadIdx.x;
+    const float ss = red[0][2 * g] + red[1][2 * g] + red[2][2 * g] + red[3][2 * g];
+    const float qq = red[0][2 * g + 1] + red[1][2 * g + 1] + red[2][2 * g + 1] + red[3][2 * g + 1];
+    const float mean = ss * inv_count;
+    st[2 * g] = mean;
+    st[2 * g + 1] = rsqrtf(fmaxf(qq * inv_count - mean * mean, 0.f) + eps);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int pix = i / nchs, c0 = (i - pix * nchs) * 8;
+    const f16x8 v = *(const f16x8*)(xb + (size_t)pix * ldx + c0);
+    const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
+    const int g1 = g0 + 1 < G ? g0 + 1 : g0;
+    const float m0 = st[2 * g0], r0 = st[2 * g0 + 1], m1 = st[2 * g1], r1 = st[2 * g1 + 1];
+    const float* ga = gamma + cs + c0;
+    const float* be = beta + cs + c0;
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool first = e < split;
+      float f = ((float)v[e] - (first ? m0 : m1)) * (first ? r0 : r1) * ga[e] + be[e];
+      if (silu) f = f / (1.0f + __expf(-f));
+      o[e] = (f16)f;
+    }
+    *(f16x8*)(yb + (size_t)pix * ldy + c0) = o;
   }
 }
 
@@ -177,7 +276,7 @@ static int gn_chunks(int HW) {
 }
 
 size_t dtp_groupnorm_ws_bytes(int B, int HW, int C, int groups) {
-  return ((size_t)B * gn_chunks(HW) * groups * 2 + (size_t)B * groups * 2) * sizeof(float);
+  return (size_t)B * gn_chunks(HW) * groups * 2 * sizeof(float);
 }
 
 int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, float* ws, int B,
@@ -188,6 +287,18 @@ int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* ga
   }
   const int cpg = C / groups;
   if (cpg < 4 || (cpg < 8 && cpg != 4)) { dtp_set_error("groupnorm: channels/group=%d unsupported", cpg); return DTP_ERR_ARG; }
+  if (HW <= 256) {
+    int G = 1;
+    while ((G * cpg) & 7) G *= 2;  // smallest slab of whole 16-byte chunks: cpg even -> G in {1, 2, 4}
+    if (G <= 4 && groups % G == 0) {
+      const float inv = 1.0f / ((float)HW * cpg);
+      dim3 grid(groups / G, B);
+      if (G == 1) hipLaunchKernelGGL((gn_fused_kernel<1>), grid, dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, HW, cpg, silu, inv, eps);
+      else if (G == 2) hipLaunchKernelGGL((gn_fused_kernel<2>), grid, dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, HW, cpg, silu, inv, eps);
+      else hipLaunchKernelGGL((gn_fused_kernel<4>), grid, dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, HW, cpg, silu, inv, eps);
+      return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+    }
+  }
   const int nch = C / 8;
   int rows = 256 / nch;
   if (rows < 1) rows = 1;
@@ -195,16 +306,13 @@ int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* ga
   if (threads > 1024) { dtp_set_error("groupnorm: C too large"); return DTP_ERR_ARG; }
   const int nchunk = gn_chunks(HW);
   const int ppc = (HW + nchunk - 1) / nchunk;
-  float* partial = ws;
-  float* stats = ws + (size_t)B * nchunk * groups * 2;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(threads), 0, s, x, ldx, partial, HW, C, cpg, groups, ppc);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, partial, stats, nchunk, groups,
-                     1.0f / ((float)HW * cpg), eps);
-  const long long total = (long long)B * HW * nch;
-  long long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, stats, HW, C, cpg,
-                     groups, silu, total);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(threads), 0, s, x, ldx, ws, HW, C, cpg, groups, ppc);
+  const long long per_batch = (long long)HW * nch;
+  long long bx = (per_batch + 255) / 256;
+  const long long cap = std::max<long long>(1, 2048 / B);
+  if (bx > cap) bx = cap;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((int)bx, B), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, ws, nchunk, HW, C, cpg,
+                     groups, silu, 1.0f / ((float)HW * cpg), eps);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 

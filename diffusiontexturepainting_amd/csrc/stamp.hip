@@ -3,6 +3,7 @@
 // Reference: trt_inference/trt_model.py:90-121, handler.py:25-33,55-56, model_base.py:51-58,
 // inpaint_pipeline.py:39-153, stable_diffusion_pipeline.py:340-355,407-484, utilities.py:370-529.
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 
 #include "engine.h"
@@ -455,10 +456,27 @@ int dtp_profile_rows(dtp_ctx* ctx, dtp_prof_row* rows, int max_rows, int* n_rows
   return DTP_OK;
 }
 
+int dtp_profile_dump(dtp_ctx* ctx, const char* path) {
+  Ctx* c = (Ctx*)ctx;
+  if (!c || !path) return DTP_ERR_ARG;
+  HIP_CHECK(hipDeviceSynchronize());
+  FILE* f = fopen(path, "w");
+  if (!f) { dtp_set_error("dtp_profile_dump: cannot open %s", path); return DTP_ERR_ARG; }
+  fprintf(f, "kind,us,tflops,algo_GBps,label\n");
+  for (const ProfRec& r : c->prof) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    fprintf(f, "%d,%.2f,%.1f,%.1f,%s\n", r.kind, ms * 1e3, r.flops / (ms * 1e-3) / 1e12, r.bytes / (ms * 1e-3) / 1e9, r.label ? r.label : "");
+  }
+  fclose(f);
+  return DTP_OK;
+}
+
 int dtp_set_option(dtp_ctx* ctx, const char* name, int value) {
   Ctx* c = (Ctx*)ctx;
   if (!c || !name) return DTP_ERR_ARG;
   if (!strcmp(name, "use_graph")) { c->use_graph = value != 0; return DTP_OK; }
+  if (!strcmp(name, "autotune")) { c->autotune = value != 0; return DTP_OK; }
   dtp_set_error("dtp_set_option: unknown option '%s'", name);
   return DTP_ERR_ARG;
 }

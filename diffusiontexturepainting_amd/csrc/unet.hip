@@ -289,6 +289,7 @@ int build_unet_prog(Ctx* c, int N, UNetProg& up) {
   b.release(x);
   RC(b.conv3(t, u.conv_out, 1, 1, false, h, h, nullptr, -1, o, GF_OUT_F32, up.out32, 4));
   b.release(t);
+  tune_cache_save(c);
   return ensure_ws(c);
 }
 

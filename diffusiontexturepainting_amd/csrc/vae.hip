@@ -141,6 +141,7 @@ int build_vae_enc_prog(Ctx* c, int B, VaeEncProg& pr) {
   T o;
   RC(b.conv3(t, v.enc_out, 1, 1, false, c->h, c->h, nullptr, -1, o, GF_OUT_F32, pr.moments, 8));
   b.release(t);
+  tune_cache_save(c);
   return ensure_ws(c);
 }
 
@@ -178,6 +179,7 @@ int build_vae_dec_prog(Ctx* c, int B, VaeDecProg& pr) {
   RC(b.gn(x, v.dec_norm_out, 1e-6f, true, t)); b.release(x);
   RC(b.conv3(t, v.dec_out, 1, 1, false, R, R, nullptr, -1, o, GF_OUT_F32, pr.out32, 4));
   b.release(t);
+  tune_cache_save(c);
   return ensure_ws(c);
 }
 

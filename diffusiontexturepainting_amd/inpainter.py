@@ -170,6 +170,9 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
         return [dict(kernel=_lib.PROF_KINDS[r.kind], launches=r.launches, ms=r.ms, flops=r.flops, bytes=r.bytes)
                 for r in rows[: n.value]]
 
+    def profile_dump(self, path):
+        check(self._lib.dtp_profile_dump(self._h, str(path).encode()), "dtp_profile_dump")
+
     def set_option(self, name, value):
         check(self._lib.dtp_set_option(self._h, name.encode(), int(value)), "dtp_set_option")
 

@@ -112,6 +112,8 @@ int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes);
 typedef struct { int kind; int launches; double ms; double flops; double bytes; } dtp_prof_row;
 int dtp_profile(dtp_ctx* ctx, int enable);
 int dtp_profile_rows(dtp_ctx* ctx, dtp_prof_row* rows, int max_rows, int* n_rows);
+/* one CSV line per recorded launch: kind,us,tflops,algo_GBps,label */
+int dtp_profile_dump(dtp_ctx* ctx, const char* path);
 /* options: "use_graph" (default 1) */
 int dtp_set_option(dtp_ctx* ctx, const char* name, int value);
 

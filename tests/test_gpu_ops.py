@@ -157,7 +157,8 @@ def test_conv3x3_strided_view_and_f32_out(ops):
 
 @pytest.mark.parametrize("b,hw,c,silu,eps", [(3, 64, 320, True, 1e-5), (2, 256, 640, False, 1e-6), (1, 1024, 128, True, 1e-6),
                                              (2, 16, 1920, True, 1e-5), (1, 100, 2560, True, 1e-5), (2, 64, 256, True, 1e-6),
-                                             (1, 64, 512, False, 1e-6), (3, 4, 960, True, 1e-5)])
+                                             (1, 64, 512, False, 1e-6), (3, 4, 960, True, 1e-5), (1, 4096, 320, True, 1e-5),
+                                             (2, 2048, 128, True, 1e-6), (1, 1600, 640, False, 1e-5)])
 def test_groupnorm(ops, b, hw, c, silu, eps):
     x = rnd(b, hw, c, seed=40) * 2 + 0.5
     g = torch.Generator().manual_seed(41)
