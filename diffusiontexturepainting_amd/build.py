@@ -17,6 +17,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 
+EXTRA = {"attention.hip": ["-ffast-math"]}  # softmax inner loop: raw v_exp_f32 / v_max3, finite sentinels only
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -34,10 +37,10 @@ def _compile(src):
     path = os.path.join(CSRC, src)
     obj = os.path.join(OBJ, src[:-4] + ".o")
     tag = obj + ".sha1"
-    want = _stamp(path, " ".join(FLAGS).encode())
+    want = _stamp(path, " ".join(FLAGS + EXTRA.get(src, [])).encode())
     if os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == want:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

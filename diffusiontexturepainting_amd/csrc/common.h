@@ -59,7 +59,7 @@ struct GemmParams {
   int flags;
 };
 
-// tile: 0 = 128x128, 1 = 128(M)x64(N), 2 = 64x64, 3 = 64(M)x128(N) ; -1 = heuristic
+// tile: shape + 4 * (stages - 2); shape 0 = 128x128, 1 = 128(M)x64(N), 2 = 64x64, 3 = 64(M)x128(N); stages 2..4
 int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s);
 int dtp_launch_splitk_reduce(const GemmParams& p, hipStream_t s);
 size_t dtp_gemm_workspace_bytes(const GemmParams& p);
@@ -93,4 +93,5 @@ int dtp_launch_nchw_f32_to_nhwc_f16(const float* x, f16* y, int B, int C, int HW
 int dtp_launch_nhwc_f16_to_nchw_f32(const f16* x, int ldx, float* y, int B, int C, int HW, hipStream_t s);
 int dtp_launch_pack_conv_weight(const float* w, f16* out, int Cout, int Cin, int Cin_pad, int taps, int ldw, hipStream_t s);
 int dtp_launch_pack_linear_weight(const float* w, f16* out, int N, int K, int ldw, const int* row_map, hipStream_t s);
+int dtp_launch_touch(const void* p, size_t bytes, float* sink, hipStream_t s);
 int dtp_launch_lora_merge(float* w, const float* up, const float* down, int N, int K, int rank, float scale, hipStream_t s);

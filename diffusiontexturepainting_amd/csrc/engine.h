@@ -200,6 +200,7 @@ struct Ctx {
   bool autotune = true;            // time every (tile, split-K) candidate of each distinct GEMM shape at build time
   std::map<std::string, std::pair<int, int>> tuned;  // shape key -> (tile, splits)
   hipEvent_t tune_ev[2] = {nullptr, nullptr};
+  void* tune_thrash = nullptr;     // 512 MiB scratch written before every timed tuning launch (cold weights)
   std::string tune_cache_path;     // $DTP_TUNE_CACHE: persisted (shape -> tile, splits) table
   size_t tune_saved = 0;
 };

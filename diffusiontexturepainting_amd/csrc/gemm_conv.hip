@@ -27,7 +27,12 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_uniform) {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-template <int BM, int BN>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NS = LDS pipeline depth: the DMA of k-block t+NS-1 is issued while k-block t is multiplied; the wait
+// before the (raw) barrier is a COUNTED vmcnt so NS-2 younger stages stay in flight across it.
+template <int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA blocks per wave along M / N
   constexpr int AR = BM / 32, WR = BN / 32;  // DMA wave-instructions per wave per k-block
@@ -126,13 +131,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   const int wn0 = (wave & 1) * (BN / 2), wm0 = (wave >> 1) * (BM / 2);
   const int frow = lane & 31, fhalf = lane >> 5;
 
-  if (nk > 0) issue(0, kb0);
+  constexpr int LOADS = AR + WR;  // DMA instructions per wave per stage
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) issue(s, kb0 + s);
+  int cur = 0, nxt = NS - 1;  // LDS buffer of k-block t / of k-block t+NS-1
   for (int t = 0; t < nk; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // stage t&1 landed for every wave; everyone is done reading stage (t+1)&1
-    if (t + 1 < nk) issue((t + 1) & 1, kb0 + t + 1);
-    const char* As = smem + (t & 1) * STAGE;
+    // k-block t has landed once at most `ahead` younger stages of this wave are still outstanding
+    const int ahead = min(NS - 2, nk - 1 - t);
+    if (NS == 2 || ahead <= 0) wait_vmcnt<0>();
+    else if (ahead == 1) wait_vmcnt<LOADS>();
+    else wait_vmcnt<(NS > 3 ? 2 * LOADS : LOADS)>();
+    __builtin_amdgcn_s_barrier();  // every wave's share of k-block t is in LDS; everyone finished reading k-block t-1
+    if (t + NS - 1 < nk) issue(nxt, kb0 + t + NS - 1);
+    const char* As = smem + cur * STAGE;
     const char* Ws = As + BM * 128;
+    cur = (cur + 1 == NS) ? 0 : cur + 1;
+    nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int c = ks * 2 + fhalf;
@@ -296,22 +311,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NS>
 int launch_tile(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  constexpr int lds = 2 * (BM + BN) * 128;
+  constexpr int lds = NS * (BM + BN) * 128;
   static_assert(lds >= BM * (BN + 8) * 2, "staging tile must fit in the pipeline buffers");
-  hipLaunchKernelGGL((gemm_kernel<BM, BN>), dim3(tiles, 1, p.splits), dim3(256), lds, s, p);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS>), dim3(tiles, 1, p.splits), dim3(256), lds, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
 }  // namespace
 
+#define FOR_ALL_VARIANTS(X) \
+  X(128, 128, 2) X(128, 128, 3) X(128, 128, 4) X(128, 64, 2) X(128, 64, 3) X(128, 64, 4) \
+  X(64, 64, 2) X(64, 64, 3) X(64, 64, 4) X(64, 128, 2) X(64, 128, 3) X(64, 128, 4)
+
 void dtp_gemm_init() {  // raise the dynamic-LDS limit once, outside any stream capture
-  (void)hipFuncSetAttribute((const void*)gemm_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128);
-  (void)hipFuncSetAttribute((const void*)gemm_kernel<128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 192 * 128);
-  (void)hipFuncSetAttribute((const void*)gemm_kernel<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128);
-  (void)hipFuncSetAttribute((const void*)gemm_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 192 * 128);
+#define SET_ATTR(BM, BN, NS) \
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128);
+  FOR_ALL_VARIANTS(SET_ATTR)
+#undef SET_ATTR
 }
 
 size_t dtp_gemm_workspace_bytes(const GemmParams& p) {
@@ -348,18 +368,20 @@ int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
   if (p.nkb <= 0 || p.M <= 0 || p.N <= 0) { dtp_set_error("gemm: empty problem"); return DTP_ERR_ARG; }
   if ((p.lda & 7) || (p.ldw & 7)) { dtp_set_error("gemm: lda/ldw must be multiples of 8"); return DTP_ERR_ARG; }
   if ((p.flags & GF_CONV3) && (p.Cin & 7)) { dtp_set_error("conv: Cin must be a multiple of 8"); return DTP_ERR_ARG; }
-  if ((p.flags & GF_GEGLU) && (p.splits > 1 || !(tile == 0 || tile == 3) || (p.N % 128))) {
+  if ((p.flags & GF_GEGLU) && (p.splits > 1 || !((tile & 3) == 0 || (tile & 3) == 3) || (p.N % 128))) {
     dtp_set_error("gemm: GEGLU needs a 128-wide N tile, N %% 128 == 0 and no split-K");
     return DTP_ERR_ARG;
   }
-  int rc;
-  switch (tile) {
-    case 0: rc = launch_tile<128, 128>(p, s); break;
-    case 1: rc = launch_tile<128, 64>(p, s); break;
-    case 2: rc = launch_tile<64, 64>(p, s); break;
-    case 3: rc = launch_tile<64, 128>(p, s); break;
-    default: dtp_set_error("gemm: bad tile id %d", tile); return DTP_ERR_ARG;
-  }
+  int rc = -1;
+  // variant id = tile + 4 * (stages - 2): tile 0..3 as documented, stages 2..4
+  const int shape = tile & 3, ns = 2 + (tile >> 2);
+  if (tile < 0 || tile >= 12) { dtp_set_error("gemm: bad tile id %d", tile); return DTP_ERR_ARG; }
+#define DISPATCH(BM, BN, NS) \
+  if (rc < 0 && ns == NS && ((BM == 128 && BN == 128 && shape == 0) || (BM == 128 && BN == 64 && shape == 1) || \
+                             (BM == 64 && BN == 64 && shape == 2) || (BM == 64 && BN == 128 && shape == 3)))       \
+    rc = launch_tile<BM, BN, NS>(p, s);
+  FOR_ALL_VARIANTS(DISPATCH)
+#undef DISPATCH
   if (rc != DTP_OK) { dtp_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
   if (p.splits > 1) return dtp_launch_splitk_reduce(p, s);
   return DTP_OK;

@@ -8,6 +8,7 @@ the stream and the noise generator; all arithmetic runs in the HIP library, and 
 library or a failing call raises (there is no fallback path).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -26,6 +27,8 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
         super().__init__()
         if not torch.cuda.is_available():
             raise _lib.DtpError("MI355ConditionalInpainter needs a ROCm GPU (torch.cuda.is_available() is False)")
+        # GEMM (tile, split-K) choices are timed once per shape at build time and persisted here
+        os.environ.setdefault("DTP_TUNE_CACHE", os.path.join(os.environ.get("TMPDIR", "/tmp"), "dtp_tune_cache.txt"))
         self._lib = _lib.load()
         self._resolution = int(resolution)
         self._index = device if isinstance(device, int) else torch.device(device).index or 0

@@ -36,7 +36,7 @@ def close(got, ref, tol=2e-3):
 
 
 @pytest.mark.parametrize("m,n,k", [(300, 320, 320), (4096, 640, 1280), (192, 1280, 2560), (77, 768, 768), (14, 1280, 768)])
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])  # shape + 4 * (pipeline stages - 2)
 def test_gemm_dense(ops, m, n, k, tile):
     a, w = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5)
     bias = torch.randn(n, generator=torch.Generator().manual_seed(3))
@@ -120,8 +120,9 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("tile", [-1, 5, 8, 10])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv3x3(ops, case):
+def test_conv3x3(ops, case, tile):
     b, h, w, cin, cout, stride, pad, ups, out_hw = case
     x = rnd(b, h, w, cin, seed=20)
     wt = rnd(cout, cin, 3, 3, seed=21, scale=(9 * cin) ** -0.5)
@@ -138,7 +139,7 @@ def test_conv3x3(ops, case):
     ref = ref.permute(0, 2, 3, 1) + res.float()
     wp = ops.pack_conv(wt.float().cuda())
     got = ops.conv3x3(x.cuda(), wp, cout, stride=stride, pad=pad, upsample=ups, bias=bias.cuda(), resid=res.cuda(),
-                      out_hw=out_hw)
+                      out_hw=out_hw, tile=tile)
     close(got, ref)
 
 

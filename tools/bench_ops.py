@@ -29,15 +29,9 @@ def gemm_suite():
         w = torch.randn(n, k, device="cuda") * k ** -0.5
         wp = ops.pack_linear(w)
         row = []
-        for tile in (0, 1, 2, 3):
-            for sp in (1, 4):
-                if sp > 1 and m > 1024:
-                    continue
-                try:
-                    t = timeit(lambda: ops.gemm(a, wp, n, k, tile=tile, splits=sp))
-                    row.append(f"t{tile}/s{sp}:{2*m*n*k/t/1e12:7.1f}TF({t*1e6:7.1f}us)")
-                except Exception as e:
-                    row.append(f"t{tile}/s{sp}: ERR")
+        for tile in range(12):
+            t = timeit(lambda: ops.gemm(a, wp, n, k, tile=tile, splits=1))
+            row.append(f"t{tile&3}n{2+tile//4}:{2*m*n*k/t/1e12:6.0f}")
         t = timeit(lambda: ops.gemm(a, wp, n, k))
         print(f"gemm M={m:6d} N={n:5d} K={k:5d} auto:{2*m*n*k/t/1e12:7.1f}TF({t*1e6:7.1f}us) | " + " ".join(row), flush=True)
 
@@ -52,12 +46,9 @@ def conv_suite():
         wp = ops.pack_conv(w)
         fl = 2.0 * b * hw * hw * cout * 9 * cin
         row = []
-        for tile in (0, 1, 2, 3):
-            for sp in (1, 4, 8):
-                if sp > 1 and b * hw * hw > 1024:
-                    continue
-                t = timeit(lambda: ops.conv3x3(x, wp, cout, tile=tile, splits=sp), iters=10)
-                row.append(f"t{tile}/s{sp}:{fl/t/1e12:6.1f}TF({t*1e6:7.1f}us)")
+        for tile in range(12):
+            t = timeit(lambda: ops.conv3x3(x, wp, cout, tile=tile, splits=1), iters=10)
+            row.append(f"t{tile&3}n{2+tile//4}:{fl/t/1e12:6.0f}")
         t = timeit(lambda: ops.conv3x3(x, wp, cout), iters=10)
         print(f"conv B={b:2d} HW={hw:3d} Cin={cin:4d} Cout={cout:4d} auto:{fl/t/1e12:6.1f}TF({t*1e6:7.1f}us) | " + " ".join(row), flush=True)
 
