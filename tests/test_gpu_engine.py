@@ -21,10 +21,11 @@ def env():
     from diffusiontexturepainting_amd import weights as W
     from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
     from oracle import nets
-    sd = dict(unet=W.synthetic_unet(1), lora=W.synthetic_lora(1), vae=W.synthetic_vae(1))
+    sd = dict(unet=W.synthetic_unet(1), lora=W.synthetic_lora(1), vae=W.synthetic_vae(1), clip=W.synthetic_clip(1),
+              penc=W.synthetic_patch_encoder(1))
     model = MI355ConditionalInpainter(R, device=0, weights=sd, max_batch=2)
     merged = nets.merge_lora(sd["unet"], sd["lora"])
-    return dict(model=model, unet=merged, vae=sd["vae"], raw_unet=sd["unet"], lora=sd["lora"])
+    return dict(model=model, unet=merged, vae=sd["vae"], raw_unet=sd["unet"], lora=sd["lora"], clip=sd["clip"], penc=sd["penc"])
 
 
 def rel_err(got, ref):
@@ -133,6 +134,53 @@ def test_stamp_u8_and_internal_noise(env):
     r2 = m.generate_raw(canvas, steps=3, context_pad=9, tg_steps=3)
     torch.cuda.synchronize()
     assert r1.shape == (1, 3, R, R) and not torch.equal(r1, r2)
+
+
+@pytest.mark.parametrize("shape", [(3, 128, 128), (3, 200, 150), (3, 224, 224), (3, 96, 160)])
+def test_set_brush_vs_oracle(env, shape):
+    """set_brush = crop_resize_square + ConditionPatchEncoder.encode_image (trt_model.py:79-88)."""
+    from oracle import image_encoder as IE, pipeline
+    img = torch.rand(*shape, generator=torch.Generator().manual_seed(shape[1]))
+    m = env["model"]
+    m.set_brush(img)
+    ref_img = pipeline.crop_resize_square(img, R).unsqueeze(0)
+    assert m.image.shape == (1, 3, R, R)
+    assert (m.image.cpu() - ref_img).abs().max().item() < 1e-5
+    emb, unc = IE.encode_image(env["clip"], env["penc"], ref_img)
+    got_e, got_u = m.conditioning
+    assert torch.equal(got_u.cpu().reshape(1, 14, 768), unc)
+    e = rel_err(got_e.reshape(1, 14, 768), emb)
+    print("image encoder rel err", e)
+    assert e < 3e-2
+    # and the conditioning is live: a stamp runs with it
+    canvas = torch.rand(1, 4, R, R)
+    out = m.generate(canvas, steps=3, context_pad=5, tg_steps=3)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+
+
+def test_engine_shim_drives_the_reference_style_loop(env):
+    """The inner boundary: the orchestration loop (oracle.pipeline.infer == InpaintPipeline.infer, pinned
+    against the reference) running on the three HIP engines through the runEngine-shaped shim."""
+    from diffusiontexturepainting_amd.engine import HipEngines
+    from oracle import pipeline
+    canvas, brush, cond, uncond, lat, eps = _stamp_inputs(1, 31)
+    draws = iter([eps[0], eps[1]])
+    eng = HipEngines(env["model"], noise_fn=lambda b, h: next(draws))
+    masked, masks, ctx_img, ctx_mask = pipeline.prepare_stamp(canvas, brush, 9)
+    run = eng.run_engine
+    out = pipeline.infer(
+        lambda s, t, c: run("unet", {"sample": s, "timestep": t, "encoder_hidden_states": c.half()})["latent"].cpu(),
+        lambda img, k: run("vae_encoder", {"images": img})["latent"].cpu(),
+        lambda z: run("vae", {"latent": z})["images"].cpu(),
+        cond, uncond, masked, masks, ctx_img, ctx_mask, lat, steps=4, cfg=2.0, tg=1.0, tg_steps=4)
+    ref = pipeline.generate_raw(dict(unet=env["unet"], vae=env["vae"]), brush, cond, uncond, canvas, lat, eps, steps=4,
+                                context_pad=9, tg_steps=4, cfg_weight=2.0, tg_weight=1.0)
+    assert (out - ref).abs().max().item() <= 1e-2
+    # engine-owned output buffers are reused across calls like the TensorRT ones
+    a = run("vae", {"latent": lat})["images"]
+    b = run("vae", {"latent": lat * 0.5})["images"]
+    assert a.data_ptr() == b.data_ptr()
 
 
 def test_errors_are_loud(env):
