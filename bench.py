@@ -114,17 +114,22 @@ def main():
             model.profile_dump(a.dump_launches)
         model.profile(False)
         tot_ms = sum(r["ms"] for r in rows)
-        dom = max(rows, key=lambda r: r["ms"])
         gem = [r for r in rows if r["kernel"].startswith("gemm_kernel")]
+        # dominant kernel = the implicit-GEMM kernel; its most time-consuming instantiation is the headline row
+        dom = max(gem, key=lambda r: r["ms"])
+        g_ms, g_fl, g_n = sum(r["ms"] for r in gem), sum(r["flops"] for r in gem), sum(r["launches"] for r in gem)
         roof = {
-            "bound": "mfma", "kernel": dom["kernel"],
-            "achieved": dom["flops"] / (dom["ms"] * 1e-3) / 1e12, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-            "frac": dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS,
-            "launches": dom["launches"], "avg_launch_us": dom["ms"] * 1e3 / dom["launches"],
-            "algorithmic_tflop_per_stamp_batch": dom["flops"] / 1e12, "traffic": None,
-            "all_gemm_tiles_achieved": sum(r["flops"] for r in gem) / (sum(r["ms"] for r in gem) * 1e-3) / 1e12,
+            "bound": "mfma", "kernel": "gemm_kernel<BM,BN,NS> (implicit-GEMM conv/linear, all instantiations)",
+            "achieved": g_fl / (g_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": g_fl / (g_ms * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS,
+            "launches": g_n, "avg_launch_us": g_ms * 1e3 / g_n, "share_of_gpu_time": g_ms / tot_ms,
+            "algorithmic_tflop_per_step": g_fl / 1e12, "traffic": None,
+            "dominant_instantiation": {"kernel": dom["kernel"], "launches": dom["launches"],
+                                       "avg_launch_us": dom["ms"] * 1e3 / dom["launches"],
+                                       "achieved": dom["flops"] / (dom["ms"] * 1e-3) / 1e12,
+                                       "frac": dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS},
             "kernels": [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["ms"], 3),
-                         "share": round(r["ms"] / tot_ms, 4),
+                         "avg_us": round(r["ms"] * 1e3 / r["launches"], 2), "share": round(r["ms"] / tot_ms, 4),
                          "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1),
                          "algo_GBps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in rows],
         }

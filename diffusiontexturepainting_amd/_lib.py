@@ -23,8 +23,10 @@ class ProfRow(C.Structure):
     _fields_ = [("kind", C.c_int), ("launches", C.c_int), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
-PROF_KINDS = ["gemm_kernel<128,128>", "gemm_kernel<128,64>", "gemm_kernel<64,64>", "gemm_kernel<64,128>", "attention_kernel",
-              "groupnorm(3 kernels)", "layernorm_kernel", "concat_kernel", "softmax_rows_kernel"]
+_SHAPES = [(128, 128), (128, 64), (64, 64), (64, 128)]
+PROF_KINDS = [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 4}>" for i in range(12)] + \
+    ["attention_kernel", "groupnorm (gn_stats+gn_apply | gn_fused)", "layernorm_kernel", "concat_kernel / small elementwise",
+     "softmax_rows_kernel"]
 
 
 class GemmDesc(C.Structure):

@@ -43,8 +43,8 @@ struct Ctx;
 
 // A launch program: a flat list of closures bound to statically planned buffers.
 using Op = std::function<int(hipStream_t, int /*step*/)>;
-// profiling classes (dtp_profile_rows): 0-3 = gemm_kernel tile variants, then the HBM-bound kernels
-enum { PK_GEMM0 = 0, PK_ATTN = 4, PK_GN = 5, PK_LN = 6, PK_ELEM = 7, PK_SOFTMAX = 8, PK_COUNT = 9 };
+// profiling classes (dtp_profile_rows): 0-11 = gemm_kernel<BM,BN,NS> variants (id = shape + 4*(NS-2)), then the rest
+enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_COUNT = 17 };
 struct ProfRec {
   int kind;
   double flops, bytes;

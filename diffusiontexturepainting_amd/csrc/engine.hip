@@ -350,7 +350,7 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg)
   char lab[160];
   snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
            p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? " geglu" : "", p.stride == 2 ? " s2" : "");
-  prog_push(c, prog, PK_GEMM0 + (tile & 3), 2.0 * p.M * (double)p.N * k_alg, bytes, [=](hipStream_t s, int step) {
+  prog_push(c, prog, PK_GEMM0 + tile, 2.0 * p.M * (double)p.N * k_alg, bytes, [=](hipStream_t s, int step) {
     GemmParams q = p;
     q.part = c->ws;
     if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;

@@ -80,7 +80,7 @@ static int vae_attention(Builder& b, const T& x, const VaeAttnW& w, T& out) {
       g.nkb = (g.K + 63) / 64;
       dtp_gemm_pick(g, &tile, c->num_cu);
       g.splits = 1; g.kb_per_split = g.nkb;
-      b.push(PK_GEMM0 + (tile & 3), 2.0 * g.M * (double)g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N),
+      b.push(PK_GEMM0 + tile, 2.0 * g.M * (double)g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N),
              [=](hipStream_t s, int) { return dtp_launch_gemm(g, tile, s); });
     };
     GemmParams g = {};

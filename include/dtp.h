@@ -104,9 +104,9 @@ int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes);
 /* ---------------------------------------------------------------- measurement
  * dtp_profile(ctx, 1): from now on every kernel launch of the engines is bracketed by HIP events on
  * the stream it runs on (graph replay is bypassed); dtp_profile_rows() aggregates them per kernel
- * class: kind 0-3 = gemm_kernel<128,128>/<128,64>/<64,64>/<64,128> (the implicit-GEMM kernel),
- * 4 = attention_kernel, 5 = GroupNorm (3 kernels), 6 = layernorm, 7 = concat/elementwise,
- * 8 = softmax_rows.  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
+ * class: kind 0-11 = gemm_kernel<BM,BN,NS> (the implicit-GEMM kernel; id = shape + 4*(NS-2), shape 0..3 =
+ * 128x128 / 128x64 / 64x64 / 64x128), 12 = attention_kernel, 13 = GroupNorm (stats+apply or fused),
+ * 14 = layernorm, 15 = concat/elementwise, 16 = softmax_rows.  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
  * dtp_profile(ctx, 0) switches back to graph replay.  The nvtx/cudaEvent hooks of
  * stable_diffusion_pipeline.py:146-149,486-503 are the reference counterpart. */
 typedef struct { int kind; int launches; double ms; double flops; double bytes; } dtp_prof_row;
