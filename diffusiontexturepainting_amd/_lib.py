@@ -35,10 +35,10 @@ class GemmDesc(C.Structure):
                 ("lda", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int),
                 ("conv", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Cin", C.c_int),
                 ("stride", C.c_int), ("pad", C.c_int), ("upsample2x", C.c_int),
-                ("flags", C.c_int), ("tile", C.c_int), ("splits", C.c_int)]
+                ("flags", C.c_int), ("tile", C.c_int), ("splits", C.c_int), ("lns", C.c_void_p), ("ln_eps", C.c_float)]
 
 
-GF_BIAS, GF_BIAS_M, GF_RESID, GF_GEGLU, GF_GELU, GF_QUICKGELU, GF_OUT_F32 = 1, 2, 4, 8, 64, 128, 256
+GF_BIAS, GF_BIAS_M, GF_RESID, GF_GEGLU, GF_GELU, GF_QUICKGELU, GF_OUT_F32, GF_SILU, GF_LNFOLD = 1, 2, 4, 8, 64, 128, 256, 512, 1024
 
 # every symbol include/dtp.h declares: name -> (restype, argtypes)
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -66,6 +66,7 @@ SYMBOLS = {
     "dtp_op_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "dtp_op_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dtp_op_pack_conv": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "dtp_op_rowsum": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "dtp_op_groupnorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "dtp_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
     "dtp_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp]),

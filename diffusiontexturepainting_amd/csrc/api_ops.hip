@@ -71,6 +71,7 @@ int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s) {
   p.nkb = (d->K + 63) / 64;
   p.Hi = d->Hi; p.Wi = d->Wi; p.Ho = d->Ho; p.Wo = d->Wo; p.Cin = d->Cin; p.stride = d->stride; p.pad = d->pad;
   p.flags = d->flags | (d->conv ? GF_CONV3 : 0) | (d->upsample2x ? GF_UPS2 : 0);
+  p.lns = d->lns; p.ln_eps = d->ln_eps;
   if (p.ldw < p.nkb * 64) { dtp_set_error("gemm: ldw=%d smaller than padded K=%d", p.ldw, p.nkb * 64); return DTP_ERR_ARG; }
   int tile = 0;
   dtp_gemm_pick(p, &tile, g_ops.num_cu);
@@ -108,6 +109,10 @@ int dtp_op_pack_linear(const float* w, void* out, int N, int K, int ldw, int geg
     map = g_ops.geglu_map;
   }
   return dtp_launch_pack_linear_weight(w, (f16*)out, N, K, ldw, map, (hipStream_t)s);
+}
+
+int dtp_op_rowsum(const void* w, int ld, int K, float* out, int rows, dtp_stream s) {
+  return dtp_launch_rowsum_f16((const f16*)w, ld, K, out, rows, (hipStream_t)s);
 }
 
 int dtp_op_pack_conv(const float* w, void* out, int Cout, int Cin, int Cin_pad, int taps, int ldw, dtp_stream s) {

@@ -26,7 +26,7 @@
 namespace {
 
 template <int DP>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1))) void attention_kernel(const AttnParams p) {
   constexpr int KS = DP / 16;           // k-steps of the QK^T contraction
   constexpr int DB = (DP + 31) / 32;    // 32-row blocks of O^T
   constexpr int KROW = DP * 2 + 16;     // K tile row stride (bytes): odd multiple of 16 -> conflict free

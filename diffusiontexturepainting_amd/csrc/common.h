@@ -39,6 +39,8 @@ enum {
   GF_QUICKGELU = 128,// out = x * sigmoid(1.702 x)
   GF_OUT_F32 = 256,  // C is fp32 (ldc in floats)
   GF_SILU = 512,     // out = x * sigmoid(x)
+  GF_LNFOLD = 1024,  // A is the RAW pre-LayerNorm tensor; W carries gamma, bias carries W.beta; the kernel computes the
+                     // row statistics itself and applies out = rstd*(acc - mean*lns[n]) + bias[n]
   GF_MFAST = 1 << 20,// internal: tile_m varies fastest (neighbouring workgroups share the W panel)
 };
 
@@ -50,6 +52,8 @@ struct GemmParams {
   const float* bias; // fp32
   const f16* R;      // residual [M][ldr]
   const f16* zero;   // >= 16 bytes of zeros in device memory (source for padded taps)
+  const float* lns;  // GF_LNFOLD: lns[n] = sum_k W'[n][k] (fp32, over the packed fp16 weights)
+  float ln_eps;
   int M, N, K;
   int lda, ldw, ldc, ldr;
   int nkb;           // number of 64-wide k-blocks in total
@@ -93,5 +97,8 @@ int dtp_launch_nchw_f32_to_nhwc_f16(const float* x, f16* y, int B, int C, int HW
 int dtp_launch_nhwc_f16_to_nchw_f32(const f16* x, int ldx, float* y, int B, int C, int HW, hipStream_t s);
 int dtp_launch_pack_conv_weight(const float* w, f16* out, int Cout, int Cin, int Cin_pad, int taps, int ldw, hipStream_t s);
 int dtp_launch_pack_linear_weight(const float* w, f16* out, int N, int K, int ldw, const int* row_map, hipStream_t s);
+int dtp_launch_rowdot(const float* w, const float* v, float* out, int N, int K, hipStream_t s);
+int dtp_launch_scale_cols(float* w, const float* g, int N, int K, hipStream_t s);
+int dtp_launch_rowsum_f16(const f16* w, int ld, int K, float* out, int rows, hipStream_t s);
 int dtp_launch_touch(const void* p, size_t bytes, float* sink, hipStream_t s);
 int dtp_launch_lora_merge(float* w, const float* up, const float* down, int N, int K, int rank, float scale, hipStream_t s);

@@ -88,6 +88,31 @@ __global__ __launch_bounds__(256) void touch_kernel(const f32x4* __restrict__ p,
   if (acc == 123.456f) *sink = acc;  // never true for real data; keeps the loads alive
 }
 
+// one wave per row helpers for the LayerNorm fold (engine.hip: load_linear with ln)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ w, const float* __restrict__ v, float* __restrict__ out,
+                                                      int N, int K) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= N) return;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += w[(size_t)row * K + k] * v[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) out[row] = acc;
+}
+__global__ __launch_bounds__(256) void scale_cols_kernel(float* __restrict__ w, const float* __restrict__ g, int N, int K) {
+  const long long total = (long long)N * K;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) w[i] *= g[i % K];
+}
+__global__ __launch_bounds__(256) void rowsum_f16_kernel(const f16* __restrict__ w, int ld, int K, float* __restrict__ out, int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += (float)w[(size_t)row * ld + k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) out[row] = acc;
+}
+
 inline int grid_for(long long total) {
   long long b = (total + 255) / 256;
   if (b > 4096) b = 4096;
@@ -135,5 +160,18 @@ int dtp_launch_touch(const void* p, size_t bytes, float* sink, hipStream_t s) {
   const long long n16 = (long long)(bytes / 16);
   if (n16 <= 0) return DTP_OK;
   hipLaunchKernelGGL(touch_kernel, dim3(grid_for(n16)), dim3(256), 0, s, (const f32x4*)p, n16, sink);
+  LAUNCH_RET();
+}
+
+int dtp_launch_rowdot(const float* w, const float* v, float* out, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(rowdot_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w, v, out, N, K);
+  LAUNCH_RET();
+}
+int dtp_launch_scale_cols(float* w, const float* g, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(scale_cols_kernel, dim3(grid_for((long long)N * K)), dim3(256), 0, s, w, g, N, K);
+  LAUNCH_RET();
+}
+int dtp_launch_rowsum_f16(const f16* w, int ld, int K, float* out, int rows, hipStream_t s) {
+  hipLaunchKernelGGL(rowsum_f16_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, w, ld, K, out, rows);
   LAUNCH_RET();
 }

@@ -25,6 +25,7 @@ struct Staged {
 struct ConvW {  // 3x3 (taps = 9) or 1x1 (taps = 1) convolution / any Linear (taps = 1)
   f16* w = nullptr;
   float* b = nullptr;  // fp32 bias (may be null)
+  float* lns = nullptr;  // LayerNorm folded in: row sums of the packed weights (GF_LNFOLD)
   int cout = 0, cin = 0 /* padded */, cin_true = 0, taps = 1, K = 0, ldw = 0;
 };
 struct NormW {
@@ -217,7 +218,8 @@ int load_norm(Ctx* c, const std::string& name, NormW& n);
 // conv weight [Cout][Cin][k][k] -> packed; cin_pad = padded input channels (>= Cin, multiple of 8)
 int load_conv(Ctx* c, const std::string& name, ConvW& w, int cin_pad = 0, bool bias = true);
 // stacked linear: rows of several [n_i][K] matrices one after another; geglu packs the [a|gate] tile order
-int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bias, bool geglu = false);
+int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bias, bool geglu = false,
+                const std::string& fold_ln = std::string());  // fold_ln: name of the LayerNorm feeding this Linear
 int load_plain_f16(Ctx* c, const std::string& name, f16** out);  // unpadded fp16 copy of a matrix
 
 // ---- builder helpers (engine.hip): every function appends ops to `prog` and returns planned buffers

@@ -124,7 +124,7 @@ int load_conv(Ctx* c, const std::string& name, ConvW& w, int cin_pad, bool bias)
   return DTP_OK;
 }
 
-int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bias, bool geglu) {
+int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bias, bool geglu, const std::string& fold_ln) {
   int N = 0, K = -1;
   for (const auto& nm : names) {
     const Staged* s = ctx_find(c, nm + ".weight");
@@ -150,6 +150,25 @@ int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bi
     HIP_CHECK(hipMalloc(&dmap, N * sizeof(int)));
     HIP_CHECK(hipMemcpy(dmap, map.data(), N * sizeof(int), hipMemcpyHostToDevice));
   }
+  // LayerNorm fold: LN(x) W^T + b = rstd * (x W'^T - mean * rowsum(W')) + (b + W beta), W' = W diag(gamma)
+  std::vector<float> wbeta;  // (W beta)[n] over the stacked rows
+  if (!fold_ln.empty()) {
+    const Staged *g = ctx_find(c, fold_ln + ".weight"), *be = ctx_find(c, fold_ln + ".bias");
+    if (!g || !be || (int)g->n != K) { dtp_set_error("LN fold: missing or mismatched norm '%s'", fold_ln.c_str()); return DTP_ERR_MISSING; }
+    float* tmp = nullptr;
+    HIP_CHECK(hipMalloc(&tmp, (size_t)N * 4));
+    int r0 = 0;
+    for (const auto& nm : names) {
+      const Staged* s = ctx_find(c, nm + ".weight");
+      const int n = (int)s->shape[0];
+      RC(dtp_launch_rowdot(s->d, be->d, tmp + r0, n, K, 0));
+      RC(dtp_launch_scale_cols(s->d, g->d, n, K, 0));
+      r0 += n;
+    }
+    wbeta.resize(N);
+    HIP_CHECK(hipMemcpy(wbeta.data(), tmp, (size_t)N * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipFree(tmp));
+  }
   int row = 0;
   for (const auto& nm : names) {
     const Staged* s = ctx_find(c, nm + ".weight");
@@ -157,16 +176,24 @@ int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bi
     RC(dtp_launch_pack_linear_weight(s->d, w.w + (size_t)row * w.ldw, n, K, w.ldw, dmap, 0));
     row += n;
   }
+  if (!fold_ln.empty()) {
+    void* pl;
+    const int rows = (int)up_to(N, 128);
+    RC(ctx_arena_alloc(c, (size_t)rows * 4, &pl));
+    w.lns = (float*)pl;
+    RC(dtp_launch_rowsum_f16(w.w, w.ldw, K, w.lns, rows, 0));
+  }
   if (dmap) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(dmap)); }
   w.b = nullptr;
-  if (bias) {
+  if (bias || !fold_ln.empty()) {
     std::vector<float> all;
     for (const auto& nm : names) {
       std::vector<float> b;
-      if (ctx_find(c, nm + ".bias")) RC(ctx_fetch_host(c, nm + ".bias", b));
+      if (bias && ctx_find(c, nm + ".bias")) RC(ctx_fetch_host(c, nm + ".bias", b));
       else b.assign((size_t)ctx_find(c, nm + ".weight")->shape[0], 0.f);
       all.insert(all.end(), b.begin(), b.end());
     }
+    for (size_t i = 0; i < wbeta.size(); ++i) all[i] += wbeta[i];
     if (geglu) {
       std::vector<float> perm(all.size());
       for (size_t i = 0; i < all.size(); ++i) perm[map[i]] = all[i];
@@ -300,7 +327,7 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
       if (geglu && !((tile & 3) == 0 || (tile & 3) == 3)) continue;
       if (p.nkb < 3 && tile >= 4) continue;
       for (int sp : cand_splits) {
-        if (sp > 1 && (geglu || p.nkb / sp < 2)) break;
+        if (sp > 1 && (geglu || (p.flags & GF_LNFOLD) || p.nkb / sp < 2)) break;
         GemmParams q = p;
         q.kb_per_split = (p.nkb + sp - 1) / sp;
         q.splits = (p.nkb + q.kb_per_split - 1) / q.kb_per_split;
@@ -393,6 +420,7 @@ int Builder::linear(const T& x, const ConvW& w, const T* resid, int flags, T& y)
   if (!y.p) return DTP_ERR_HIP;
   p.C = y.p; p.ldc = y.ld;
   if (w.b) { p.flags |= GF_BIAS; p.bias = w.b; }
+  if (w.lns) { p.flags |= GF_LNFOLD; p.lns = w.lns; p.ln_eps = 1e-5f; }  // x is the raw pre-LayerNorm tensor
   if (resid) { p.flags |= GF_RESID; p.R = resid->p; p.ldr = resid->ld; }
   return push_gemm(c, prog, p, -1, (double)w.K);
 }

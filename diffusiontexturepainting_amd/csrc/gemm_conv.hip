@@ -135,6 +135,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) issue(s, kb0 + s);
+  // ---- fused LayerNorm (GF_LNFOLD): while the first DMA stages are in flight, compute mean / rstd of this tile's
+  // BM rows over the full K = C columns (16 lanes per row, 16-byte loads; the rows are L2/Infinity-Cache resident:
+  // they were written by the previous kernel).  Applied in the epilogue, so the normalised tensor never exists.
+  float* rowst = (float*)(smem + NS * STAGE);
+  if (p.flags & GF_LNFOLD) {
+    const int l16 = tid & 15, nch = p.K >> 3;
+    for (int r0 = 0; r0 < BM; r0 += 16) {
+      const int r = r0 + (tid >> 4), m = m0 + r;
+      float s1 = 0.f, s2 = 0.f;
+      if (m < p.M) {
+        const f16* row = p.A + (size_t)m * p.lda;
+        for (int c = l16; c < nch; c += 16) {
+          const f16x8 v = *(const f16x8*)(row + c * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 += f * f; }
+        }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      if (l16 == 0) {
+        const float mean = s1 / (float)p.K;
+        const float var = fmaxf(s2 / (float)p.K - mean * mean, 0.f);
+        rowst[2 * r] = mean;
+        rowst[2 * r + 1] = rsqrtf(var + p.ln_eps);
+      }
+    }
+  }
   int cur = 0, nxt = NS - 1;  // LDS buffer of k-block t / of k-block t+NS-1
   for (int t = 0; t < nk; ++t) {
     // k-block t has landed once at most `ahead` younger stages of this wave are still outstanding
@@ -226,9 +253,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       const float* ba = p.bias + n0 + nc * 8;
       const float* bg = ba + BN / 2;
       f16x8 o;
+      const float mean = rowst[2 * ml], rstd = rowst[2 * ml + 1];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float av = (float)a[e], gv = (float)g[e];
+        if (fl & GF_LNFOLD) {
+          av = rstd * (av - mean * p.lns[n0 + nc * 8 + e]);
+          gv = rstd * (gv - mean * p.lns[n0 + BN / 2 + nc * 8 + e]);
+        }
         if (fl & GF_BIAS) { av += ba[e]; gv += bg[e]; }
         o[e] = (f16)(av * gelu_erf(gv));
       }
@@ -248,6 +280,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
     const bool full = (n + 8 <= p.N);
+    if (fl & GF_LNFOLD) {
+      const float mean = rowst[2 * ml], rstd = rowst[2 * ml + 1];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (full || n + e < p.N) x[e] = rstd * (x[e] - mean * p.lns[n + e]);
+    }
     if (fl & GF_BIAS) {
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -314,8 +352,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 template <int BM, int BN, int NS>
 int launch_tile(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  constexpr int lds = NS * (BM + BN) * 128;
-  static_assert(lds >= BM * (BN + 8) * 2, "staging tile must fit in the pipeline buffers");
+  constexpr int lds = NS * (BM + BN) * 128 + 1024;  // + per-row LayerNorm statistics
+  static_assert(lds - 1024 >= BM * (BN + 8) * 2, "staging tile must fit in the pipeline buffers");
   static_assert(lds <= 160 * 1024, "LDS budget");
   hipLaunchKernelGGL((gemm_kernel<BM, BN, NS>), dim3(tiles, 1, p.splits), dim3(256), lds, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
@@ -329,7 +367,7 @@ int launch_tile(const GemmParams& p, hipStream_t s) {
 
 void dtp_gemm_init() {  // raise the dynamic-LDS limit once, outside any stream capture
 #define SET_ATTR(BM, BN, NS) \
-  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + 1024);
   FOR_ALL_VARIANTS(SET_ATTR)
 #undef SET_ATTR
 }
@@ -349,7 +387,7 @@ void dtp_gemm_pick(GemmParams& p, int* tile, int num_cu) {
   static const int bm[4] = {128, 128, 64, 64}, bn[4] = {128, 64, 64, 128};
   const long long blocks = (long long)((p.M + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]);
   int splits = 1;
-  if (!geglu && blocks * 2 <= num_cu && p.nkb >= 8) {
+  if (!geglu && !(p.flags & GF_LNFOLD) && blocks * 2 <= num_cu && p.nkb >= 8) {
     splits = (int)((2LL * num_cu + blocks - 1) / blocks);
     if (splits > p.nkb / 4) splits = p.nkb / 4;
     if (splits > 32) splits = 32;
@@ -368,6 +406,10 @@ int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
   if (p.nkb <= 0 || p.M <= 0 || p.N <= 0) { dtp_set_error("gemm: empty problem"); return DTP_ERR_ARG; }
   if ((p.lda & 7) || (p.ldw & 7)) { dtp_set_error("gemm: lda/ldw must be multiples of 8"); return DTP_ERR_ARG; }
   if ((p.flags & GF_CONV3) && (p.Cin & 7)) { dtp_set_error("conv: Cin must be a multiple of 8"); return DTP_ERR_ARG; }
+  if ((p.flags & GF_LNFOLD) && (p.splits > 1 || (p.flags & GF_CONV3) || !p.lns)) {
+    dtp_set_error("gemm: LayerNorm fold needs a dense, unsplit GEMM with lns");
+    return DTP_ERR_ARG;
+  }
   if ((p.flags & GF_GEGLU) && (p.splits > 1 || !((tile & 3) == 0 || (tile & 3) == 3) || (p.N % 128))) {
     dtp_set_error("gemm: GEGLU needs a 128-wide N tile, N %% 128 == 0 and no split-K");
     return DTP_ERR_ARG;

@@ -268,8 +268,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* __restrict
 
 }  // namespace
 
-static int gn_chunks(int HW) {
-  int n = HW / 64;
+static int gn_chunks(int HW) {  // pixel chunks per batch item for the statistics pass (more chunks = more loads in flight)
+  int n = HW / 16;
   if (n < 1) n = 1;
   if (n > 256) n = 256;
   return n;
@@ -309,7 +309,7 @@ int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* ga
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(threads), 0, s, x, ldx, ws, HW, C, cpg, groups, ppc);
   const long long per_batch = (long long)HW * nch;
   long long bx = (per_batch + 255) / 256;
-  const long long cap = std::max<long long>(1, 2048 / B);
+  const long long cap = std::max<long long>(1, 768 / B);  // every block re-reduces the partials of its batch item
   if (bx > cap) bx = cap;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((int)bx, B), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, ws, nchunk, HW, C, cpg,
                      groups, silu, 1.0f / ((float)HW * cpg), eps);

@@ -30,12 +30,13 @@ static int load_xf(Ctx* c, const std::string& p, XfW& w, int& kv_counter) {
   RC(load_norm(c, t + ".norm1", w.ln1));
   RC(load_norm(c, t + ".norm2", w.ln2));
   RC(load_norm(c, t + ".norm3", w.ln3));
-  RC(load_linear(c, {t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"}, w.qkv, false));
+  // the three LayerNorms are folded into the Linear that consumes them (GF_LNFOLD): no LN kernel, no LN tensor
+  RC(load_linear(c, {t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"}, w.qkv, false, false, t + ".norm1"));
   RC(load_linear(c, {t + ".attn1.to_out.0"}, w.out1, true));
-  RC(load_linear(c, {t + ".attn2.to_q"}, w.q2, false));
+  RC(load_linear(c, {t + ".attn2.to_q"}, w.q2, false, false, t + ".norm2"));
   RC(load_linear(c, {t + ".attn2.to_k", t + ".attn2.to_v"}, w.kv2, false));
   RC(load_linear(c, {t + ".attn2.to_out.0"}, w.out2, true));
-  RC(load_linear(c, {t + ".ff.net.0.proj"}, w.ff1, true, true));
+  RC(load_linear(c, {t + ".ff.net.0.proj"}, w.ff1, true, true, t + ".norm3"));
   RC(load_linear(c, {t + ".ff.net.2"}, w.ff2, true));
   RC(load_conv(c, p + ".proj_out", w.proj_out));
   w.kv_index = kv_counter++;
@@ -160,9 +161,7 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
   RC(b.gn(x, w.gn, 1e-6f, false, t));
   RC(b.linear(t, w.proj_in, nullptr, 0, y));
   b.release(t);
-  RC(b.ln(y, w.ln1, n1));
-  RC(b.linear(n1, w.qkv, nullptr, 0, qkv));
-  b.release(n1);
+  RC(b.linear(y, w.qkv, nullptr, 0, qkv));  // LN1 folded
   T q = qkv, k = qkv, v = qkv;
   q.C = k.C = v.C = C;
   k.p += C; v.p += 2 * C;
@@ -171,9 +170,7 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
   a.B = x.B; a.H = x.H; a.W = x.W;
   RC(b.linear(a, w.out1, &y, 0, y2));
   b.release(a); b.release(y);
-  RC(b.ln(y2, w.ln2, n2));
-  RC(b.linear(n2, w.q2, nullptr, 0, q2));
-  b.release(n2);
+  RC(b.linear(y2, w.q2, nullptr, 0, q2));  // LN2 folded
   T kk, vv;
   kk.p = up.kvbuf[w.kv_index]; kk.B = N; kk.H = 1; kk.W = 14; kk.C = C; kk.ld = 2 * C;
   vv = kk; vv.p += C;
@@ -182,9 +179,7 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
   a2.B = x.B; a2.H = x.H; a2.W = x.W;
   RC(b.linear(a2, w.out2, &y2, 0, y3));
   b.release(a2); b.release(y2);
-  RC(b.ln(y3, w.ln3, n3));
-  RC(b.linear(n3, w.ff1, nullptr, GF_GEGLU, f));
-  b.release(n3);
+  RC(b.linear(y3, w.ff1, nullptr, GF_GEGLU, f));  // LN3 folded
   RC(b.linear(f, w.ff2, &y3, 0, y4));
   b.release(f); b.release(y3);
   RC(b.linear(y4, w.proj_out, &x, 0, out));

@@ -8,7 +8,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import GF_BIAS, GF_BIAS_M, GF_GEGLU, GF_GELU, GF_OUT_F32, GF_QUICKGELU, GF_RESID, GemmDesc, check, ptr
+from ._lib import (GF_BIAS, GF_BIAS_M, GF_GEGLU, GF_GELU, GF_LNFOLD, GF_OUT_F32, GF_QUICKGELU, GF_RESID, GemmDesc, check,
+                   ptr)
 
 
 def _stream():
@@ -40,7 +41,15 @@ def pack_conv(w, cin_pad=None):
     return out
 
 
-def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, out=None, lda=None):
+def rowsum(wp, k):
+    """fp32 row sums of packed fp16 weights over the first k columns (the `lns` vector of a LayerNorm-folded GEMM)."""
+    lib = _lib.load()
+    out = torch.empty(wp.shape[0], dtype=torch.float32, device=wp.device)
+    check(lib.dtp_op_rowsum(ptr(wp), wp.stride(0), k, ptr(out), wp.shape[0], _stream()), "rowsum")
+    return out
+
+
+def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, out=None, lda=None, lns=None, ln_eps=1e-5):
     """a f16 [M, >=K] row-major; wp packed weights; returns f16 [M, N] (or [M, N/2] with GEGLU)."""
     lib = _lib.load()
     m = a.shape[0]
@@ -57,6 +66,9 @@ def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, ou
     d.ldr = resid.stride(0) if resid is not None else 0
     d.flags = flags | (GF_BIAS if bias is not None and not flags & GF_BIAS_M else 0) | (GF_RESID if resid is not None else 0)
     d.tile, d.splits = tile, splits
+    if lns is not None:
+        d.lns, d.ln_eps = lns.data_ptr(), ln_eps
+        d.flags |= GF_LNFOLD
     check(lib.dtp_op_gemm(C.byref(d), _stream()), "gemm")
     return out
 

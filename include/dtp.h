@@ -133,14 +133,18 @@ typedef struct {
   int flags;         /* DTP_GF_* */
   int tile;          /* -1 = heuristic; 0:128x128 1:128x64 2:64x64 3:64x128 (MxN) */
   int splits;        /* 0 = heuristic; >=1 = forced split-K factor */
+  const float* lns;  /* DTP_GF_LNFOLD: row sums of the packed weights (dtp_op_rowsum) */
+  float ln_eps;
 } dtp_gemm_desc;
 enum { DTP_GF_BIAS = 1, DTP_GF_BIAS_M = 2, DTP_GF_RESID = 4, DTP_GF_GEGLU = 8, DTP_GF_GELU = 64, DTP_GF_QUICKGELU = 128,
-       DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512 };
+       DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512, DTP_GF_LNFOLD = 1024 };
 
 int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s);
 /* w f32 [N][K] -> out f16 [rows][ldw] (caller zero-fills out); geglu=1 applies the [a|gate] tile packing */
 int dtp_op_pack_linear(const float* w, void* out, int N, int K, int ldw, int geglu, dtp_stream s);
 /* w f32 [Cout][Cin][3][3] (or 1x1) -> out f16 [rows][ldw], k = tap*Cin_pad + ci (caller zero-fills out) */
+/* out[r] = sum_k w[r][k] over packed fp16 rows (the `lns` vector of a LayerNorm-folded GEMM) */
+int dtp_op_rowsum(const void* w, int ld, int K, float* out, int rows, dtp_stream s);
 int dtp_op_pack_conv(const float* w, void* out, int Cout, int Cin, int Cin_pad, int taps, int ldw, dtp_stream s);
 int dtp_op_groupnorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
                      int groups, float eps, int silu, dtp_stream s);

@@ -90,6 +90,33 @@ def test_gemm_geglu(ops, m, c):
     close(got, ref)
 
 
+@pytest.mark.parametrize("m,c,n,tile,geglu", [(300, 320, 960, -1, False), (100, 1280, 1280, 6, False), (513, 640, 5120, -1, True),
+                                             (64, 768, 768, 3, False)])
+def test_gemm_layernorm_fold(ops, m, c, n, tile, geglu):
+    """LN(x) W^T + b computed from the RAW x: W carries gamma, bias carries W.beta, statistics in-kernel."""
+    from diffusiontexturepainting_amd._lib import GF_BIAS, GF_GEGLU
+    x = rnd(m, c, seed=90) * 1.7 + 0.4
+    w = rnd(n, c, seed=91, scale=c ** -0.5).float()
+    g = torch.Generator().manual_seed(92)
+    gamma, beta, bias = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(n, generator=g)
+    ref = F.linear(F.layer_norm(x.float(), (c,), gamma, beta, 1e-5), w, bias)
+    b2 = bias + w @ beta
+    if geglu:
+        a, gate = ref.chunk(2, dim=-1)
+        ref = a * F.gelu(gate)
+        f = torch.arange(n // 2)
+        perm = torch.empty(n, dtype=torch.long)
+        perm[f] = (f // 64) * 128 + f % 64
+        perm[n // 2 + f] = (f // 64) * 128 + 64 + f % 64
+        bp = torch.empty_like(b2)
+        bp[perm] = b2
+        b2 = bp
+    wp = ops.pack_linear((w * gamma[None]).cuda(), geglu=geglu)
+    lns = ops.rowsum(wp, c)
+    got = ops.gemm(x.cuda(), wp, n, c, bias=b2.cuda(), lns=lns, tile=tile, flags=(GF_GEGLU | GF_BIAS) if geglu else 0)
+    close(got, ref, tol=3e-3)
+
+
 def test_gemm_epilogues(ops):
     from diffusiontexturepainting_amd._lib import GF_BIAS_M, GF_GELU, GF_QUICKGELU
     m, n, k = 130, 256, 192
