@@ -39,8 +39,9 @@ enum {
   GF_QUICKGELU = 128,// out = x * sigmoid(1.702 x)
   GF_OUT_F32 = 256,  // C is fp32 (ldc in floats)
   GF_SILU = 512,     // out = x * sigmoid(x)
-  GF_LNFOLD = 1024,  // A is the RAW pre-LayerNorm tensor; W carries gamma, bias carries W.beta; the kernel computes the
-                     // row statistics itself and applies out = rstd*(acc - mean*lns[n]) + bias[n]
+  GF_LNFOLD = 1024,  // A is the RAW pre-LayerNorm tensor; W carries gamma, bias carries W.beta; row statistics come from
+                     // the producer (st_in) or are computed in-kernel; out = rstd*(acc - mean*lns[n]) + bias[n]
+  GF_ROWSTATS = 2048,// also emit per-row (sum, sum of squares) of the fp16 output, one partial per N tile -> st_out
   GF_MFAST = 1 << 20,// internal: tile_m varies fastest (neighbouring workgroups share the W panel)
 };
 
@@ -54,6 +55,9 @@ struct GemmParams {
   const f16* zero;   // >= 16 bytes of zeros in device memory (source for padded taps)
   const float* lns;  // GF_LNFOLD: lns[n] = sum_k W'[n][k] (fp32, over the packed fp16 weights)
   float ln_eps;
+  const float* st_in;  // GF_LNFOLD: [st_parts][M][2] partial (sum, sumsq) of the rows of A; null = compute in-kernel
+  int st_parts;
+  float* st_out;       // GF_ROWSTATS: [tiles_n][M][2]
   int M, N, K;
   int lda, ldw, ldc, ldr;
   int nkb;           // number of 64-wide k-blocks in total

@@ -222,6 +222,12 @@ int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bi
                 const std::string& fold_ln = std::string());  // fold_ln: name of the LayerNorm feeding this Linear
 int load_plain_f16(Ctx* c, const std::string& name, f16** out);  // unpadded fp16 copy of a matrix
 
+// per-row (sum, sumsq) partials handed from a producer GEMM (GF_ROWSTATS) to the LayerNorm-folded consumer
+struct RowStats {
+  float* buf = nullptr;  // [parts][M][2]
+  int parts = 0, M = 0;
+};
+
 // ---- builder helpers (engine.hip): every function appends ops to `prog` and returns planned buffers
 struct Builder {
   Ctx* c;
@@ -235,7 +241,9 @@ struct Builder {
   // conv3x3; bias_step_off >= 0 selects the per-step bias slice from the temb table instead of w.b
   int conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, int Ho, int Wo, const T* resid, int bias_step_off,
             T& y, int extra_flags = 0, void* out_override = nullptr, int ldc_override = 0);
-  int linear(const T& x, const ConvW& w, const T* resid, int flags, T& y);
+  int linear(const T& x, const ConvW& w, const T* resid, int flags, T& y, RowStats* emit = nullptr, const RowStats* use = nullptr);
+  int alloc_stats(long long rows, int C, RowStats& st);  // room for one partial per 64-column tile
+  void release_stats(RowStats& st);
   int attention(const T& q, const T& k, const T& v, int heads, int Sq, int Skv, int Bn, T& o);
   int concat(const T& a, const T& b, T& y);
   int resnet(const T& x, const ResW& w, float eps, bool temb, T& y);

@@ -311,8 +311,8 @@ void tune_cache_save(Ctx* c) {
 // with every tile variant x split-K factor on the real buffers and the fastest pair is kept.
 static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   char key[200];
-  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin, p.stride,
-           p.lda, p.ldc, p.ldw);
+  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin, p.stride,
+           p.lda, p.ldc, p.ldw, p.st_parts);
   auto it = c->tuned.find(key);
   if (it == c->tuned.end()) {
     if (!c->tune_ev[0]) { HIP_CHECK(hipEventCreate(&c->tune_ev[0])); HIP_CHECK(hipEventCreate(&c->tune_ev[1])); }
@@ -363,10 +363,15 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   return DTP_OK;
 }
 
-int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg) {
+int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg, RowStats* emit = nullptr) {
   int tile = 0;
   dtp_gemm_pick(p, &tile, c->num_cu);
   if (c->autotune) RC(tune_gemm(c, p, &tile));
+  if (emit) {  // the consumer must know how many partials this launch configuration writes per row
+    static const int bn[4] = {128, 64, 64, 128};
+    emit->parts = p.splits > 1 ? 1 : (p.N + bn[tile & 3] - 1) / bn[tile & 3];
+    emit->M = p.M;
+  }
   c->ws_need = std::max(c->ws_need, dtp_gemm_workspace_bytes(p));
   p.zero = c->zero;
   // algorithmic work: 2*M*N*K on the UNPADDED contraction; bytes = A once + W once + C once (fp16)
@@ -409,7 +414,17 @@ int Builder::conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, in
   return push_gemm(c, prog, p, bias_step_off, 9.0 * w.cin_true);
 }
 
-int Builder::linear(const T& x, const ConvW& w, const T* resid, int flags, T& y) {
+int Builder::alloc_stats(long long rows, int C, RowStats& st) {
+  void* p = nullptr;
+  RC(ctx_pool_get(c, (size_t)((C + 63) / 64) * rows * 2 * sizeof(float), &p));
+  st.buf = (float*)p;
+  st.parts = 0;
+  st.M = (int)rows;
+  return DTP_OK;
+}
+void Builder::release_stats(RowStats& st) { ctx_pool_put(c, st.buf); st.buf = nullptr; }
+
+int Builder::linear(const T& x, const ConvW& w, const T* resid, int flags, T& y, RowStats* emit, const RowStats* use) {
   if (x.C != w.K || w.taps != 1) { dtp_set_error("linear: K mismatch %d vs %d", x.C, w.K); return DTP_ERR_ARG; }
   GemmParams p = {};
   p.A = x.p; p.W = w.w;
@@ -420,9 +435,13 @@ int Builder::linear(const T& x, const ConvW& w, const T* resid, int flags, T& y)
   if (!y.p) return DTP_ERR_HIP;
   p.C = y.p; p.ldc = y.ld;
   if (w.b) { p.flags |= GF_BIAS; p.bias = w.b; }
-  if (w.lns) { p.flags |= GF_LNFOLD; p.lns = w.lns; p.ln_eps = 1e-5f; }  // x is the raw pre-LayerNorm tensor
+  if (w.lns) {  // x is the raw pre-LayerNorm tensor
+    p.flags |= GF_LNFOLD; p.lns = w.lns; p.ln_eps = 1e-5f;
+    if (use && use->buf && use->parts > 0 && use->M == p.M) { p.st_in = use->buf; p.st_parts = use->parts; }
+  }
   if (resid) { p.flags |= GF_RESID; p.R = resid->p; p.ldr = resid->ld; }
-  return push_gemm(c, prog, p, -1, (double)w.K);
+  if (emit && emit->buf) { p.flags |= GF_ROWSTATS; p.st_out = emit->buf; }
+  return push_gemm(c, prog, p, -1, (double)w.K, (emit && emit->buf) ? emit : nullptr);
 }
 
 int Builder::attention(const T& q, const T& k, const T& v, int heads, int Sq, int Skv, int Bn, T& o) {

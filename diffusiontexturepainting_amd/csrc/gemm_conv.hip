@@ -139,7 +139,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   // BM rows over the full K = C columns (16 lanes per row, 16-byte loads; the rows are L2/Infinity-Cache resident:
   // they were written by the previous kernel).  Applied in the epilogue, so the normalised tensor never exists.
   float* rowst = (float*)(smem + NS * STAGE);
-  if (p.flags & GF_LNFOLD) {
+  if ((p.flags & GF_LNFOLD) && p.st_in) {
+    // statistics were emitted by the producer of A (GF_ROWSTATS): combine its per-N-tile partials
+    for (int r = tid; r < BM; r += 256) {
+      const int m = m0 + r;
+      float s1 = 0.f, s2 = 0.f;
+      if (m < p.M)
+        for (int q = 0; q < p.st_parts; ++q) {
+          s1 += p.st_in[((size_t)q * p.M + m) * 2];
+          s2 += p.st_in[((size_t)q * p.M + m) * 2 + 1];
+        }
+      const float mean = s1 / (float)p.K;
+      rowst[2 * r] = mean;
+      rowst[2 * r + 1] = rsqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + p.ln_eps);
+    }
+  } else if (p.flags & GF_LNFOLD) {
     const int l16 = tid & 15, nch = p.K >> 3;
     for (int r0 = 0; r0 < BM; r0 += 16) {
       const int r = r0 + (tid >> 4), m = m0 + r;
@@ -250,18 +264,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       if (m >= p.M) continue;
       const f16x8 a = *(const f16x8*)(stg + ml * SLD + nc * 8);
       const f16x8 g = *(const f16x8*)(stg + ml * SLD + BN / 2 + nc * 8);
-      const float* ba = p.bias + n0 + nc * 8;
-      const float* bg = ba + BN / 2;
+      // bias / lns are read as whole 16-byte vectors up front: per-element conditional loads make hipcc wait
+      // vmcnt(0) after every single dword (N % 128 == 0 here, so the vectors are always in range)
+      float ba[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, la[8], lg[8];
+      if (fl & GF_BIAS) {
+        const f32x4 t0 = *(const f32x4*)(p.bias + n0 + nc * 8), t1 = *(const f32x4*)(p.bias + n0 + nc * 8 + 4);
+        const f32x4 u0 = *(const f32x4*)(p.bias + n0 + BN / 2 + nc * 8), u1 = *(const f32x4*)(p.bias + n0 + BN / 2 + nc * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ba[e] = t0[e]; ba[4 + e] = t1[e]; bg[e] = u0[e]; bg[4 + e] = u1[e]; }
+      }
+      float mean = 0.f, rstd = 1.f;
+      if (fl & GF_LNFOLD) {
+        const f32x4 t0 = *(const f32x4*)(p.lns + n0 + nc * 8), t1 = *(const f32x4*)(p.lns + n0 + nc * 8 + 4);
+        const f32x4 u0 = *(const f32x4*)(p.lns + n0 + BN / 2 + nc * 8), u1 = *(const f32x4*)(p.lns + n0 + BN / 2 + nc * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { la[e] = t0[e]; la[4 + e] = t1[e]; lg[e] = u0[e]; lg[4 + e] = u1[e]; }
+        mean = rowst[2 * ml]; rstd = rowst[2 * ml + 1];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) la[e] = lg[e] = 0.f;
+      }
       f16x8 o;
-      const float mean = rowst[2 * ml], rstd = rowst[2 * ml + 1];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float av = (float)a[e], gv = (float)g[e];
-        if (fl & GF_LNFOLD) {
-          av = rstd * (av - mean * p.lns[n0 + nc * 8 + e]);
-          gv = rstd * (gv - mean * p.lns[n0 + BN / 2 + nc * 8 + e]);
-        }
-        if (fl & GF_BIAS) { av += ba[e]; gv += bg[e]; }
+        const float av = rstd * ((float)a[e] - mean * la[e]) + ba[e];
+        const float gv = rstd * ((float)g[e] - mean * lg[e]) + bg[e];
         o[e] = (f16)(av * gelu_erf(gv));
       }
       *(f16x8*)(C + (size_t)m * p.ldc + tile_n * (BN / 2) + nc * 8) = o;
@@ -271,60 +298,95 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
   constexpr int NC = BN / 8;
   const bool vec_ok = ((p.ldc & 7) == 0) && !(fl & GF_OUT_F32) && (!(fl & GF_RESID) || (p.ldr & 7) == 0);
-  for (int idx = tid; idx < BM * NC; idx += 256) {
+  for (int idx = tid; idx < BM * NC; idx += 256) {  // BM*NC is a multiple of 256: every lane runs every iteration
     const int ml = idx / NC, nc = idx - ml * NC;
     const int m = m0 + ml, n = n0 + nc * 8;
-    if (m >= p.M || n >= p.N) continue;
-    const f16x8 v = *(const f16x8*)(stg + ml * SLD + nc * 8);
-    float x[8];
+    const bool active = (m < p.M) && (n < p.N);
+    float s1 = 0.f, s2 = 0.f;
+    if (active) {
+      const f16x8 v = *(const f16x8*)(stg + ml * SLD + nc * 8);
+      float x[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
-    const bool full = (n + 8 <= p.N);
-    if (fl & GF_LNFOLD) {
-      const float mean = rowst[2 * ml], rstd = rowst[2 * ml + 1];
+      for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
+      const bool full = (n + 8 <= p.N);
+      // per-column vectors (bias, lns) as whole 16-byte loads when the chunk is complete; guarded scalars on the N tail
+      float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (full) {
+        if (fl & GF_BIAS) {
+          const f32x4 t0 = *(const f32x4*)(p.bias + n), t1 = *(const f32x4*)(p.bias + n + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (full || n + e < p.N) x[e] = rstd * (x[e] - mean * p.lns[n + e]);
-    }
-    if (fl & GF_BIAS) {
+          for (int e = 0; e < 4; ++e) { bv[e] = t0[e]; bv[4 + e] = t1[e]; }
+        }
+        if (fl & GF_LNFOLD) {
+          const f32x4 t0 = *(const f32x4*)(p.lns + n), t1 = *(const f32x4*)(p.lns + n + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (full || n + e < p.N) x[e] += p.bias[n + e];
-    }
-    if (fl & GF_BIAS_M) {
-      const float bm = p.bias[m];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] += bm;
-    }
-    if (fl & GF_GELU) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = gelu_erf(x[e]);
-    }
-    if (fl & GF_QUICKGELU) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = x[e] / (1.0f + __expf(-1.702f * x[e]));
-    }
-    if (fl & GF_SILU) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = x[e] / (1.0f + __expf(-x[e]));
-    }
-    if (full && vec_ok) {
-      if (fl & GF_RESID) {
-        const f16x8 r = *(const f16x8*)(p.R + (size_t)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] += (float)r[e];
+          for (int e = 0; e < 4; ++e) { lv[e] = t0[e]; lv[4 + e] = t1[e]; }
+        }
+      } else {
+        for (int e = 0; e < 8 && n + e < p.N; ++e) {
+          if (fl & GF_BIAS) bv[e] = p.bias[n + e];
+          if (fl & GF_LNFOLD) lv[e] = p.lns[n + e];
+        }
       }
-      f16x8 o;
+      if (fl & GF_LNFOLD) {
+        const float mean = rowst[2 * ml], rstd = rowst[2 * ml + 1];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (f16)x[e];
-      *(f16x8*)((f16*)p.C + (size_t)m * p.ldc + n) = o;
-    } else {
-      for (int e = 0; e < 8; ++e) {
-        if (n + e >= p.N) break;
-        float y = x[e];
-        if (fl & GF_RESID) y += (float)p.R[(size_t)m * p.ldr + n + e];
-        if (fl & GF_OUT_F32) ((float*)p.C)[(size_t)m * p.ldc + n + e] = y;
-        else ((f16*)p.C)[(size_t)m * p.ldc + n + e] = (f16)y;
+        for (int e = 0; e < 8; ++e) x[e] = rstd * (x[e] - mean * lv[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += bv[e];
+      if (fl & GF_BIAS_M) {
+        const float bm = p.bias[m];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += bm;
+      }
+      if (fl & GF_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = gelu_erf(x[e]);
+      }
+      if (fl & GF_QUICKGELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = x[e] / (1.0f + __expf(-1.702f * x[e]));
+      }
+      if (fl & GF_SILU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = x[e] / (1.0f + __expf(-x[e]));
+      }
+      if (full && vec_ok) {
+        if (fl & GF_RESID) {
+          const f16x8 r = *(const f16x8*)(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] += (float)r[e];
+        }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o[e] = (f16)x[e];
+          const float f = (float)o[e];  // statistics of what the consumer will actually read
+          s1 += f; s2 += f * f;
+        }
+        *(f16x8*)((f16*)p.C + (size_t)m * p.ldc + n) = o;
+      } else {
+        for (int e = 0; e < 8; ++e) {
+          if (n + e >= p.N) break;
+          float y = x[e];
+          if (fl & GF_RESID) y += (float)p.R[(size_t)m * p.ldr + n + e];
+          if (fl & GF_OUT_F32) ((float*)p.C)[(size_t)m * p.ldc + n + e] = y;
+          else {
+            const f16 h = (f16)y;
+            ((f16*)p.C)[(size_t)m * p.ldc + n + e] = h;
+            y = (float)h;
+          }
+          s1 += y; s2 += y * y;
+        }
+      }
+    }
+    if (fl & GF_ROWSTATS) {  // NC consecutive lanes hold one row of this N tile: fixed-order shuffle reduce
+#pragma unroll
+      for (int o = NC / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      if (nc == 0 && m < p.M) {
+        p.st_out[((size_t)tile_n * p.M + m) * 2] = s1;
+        p.st_out[((size_t)tile_n * p.M + m) * 2 + 1] = s2;
       }
     }
   }
@@ -347,6 +409,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     if (fl & GF_OUT_F32) ((float*)p.C)[(size_t)m * p.ldc + n] = x;
     else ((f16*)p.C)[(size_t)m * p.ldc + n] = (f16)x;
   }
+}
+
+// split-K reduce that also emits row statistics (GF_ROWSTATS): one wave per output row, st_parts = 1
+__global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParams p) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= p.M) return;
+  const size_t total = (size_t)p.M * p.N;
+  const int fl = p.flags;
+  float s1 = 0.f, s2 = 0.f;
+  for (int n = lane; n < p.N; n += 64) {
+    const size_t i = (size_t)m * p.N + n;
+    float x = 0.f;
+    for (int z = 0; z < p.splits; ++z) x += p.part[(size_t)z * total + i];
+    if (fl & GF_BIAS) x += p.bias[n];
+    if (fl & GF_RESID) x += (float)p.R[(size_t)m * p.ldr + n];
+    const f16 h = (f16)x;
+    ((f16*)p.C)[(size_t)m * p.ldc + n] = h;
+    const float f = (float)h;
+    s1 += f; s2 += f * f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  if (lane == 0) { p.st_out[(size_t)m * 2] = s1; p.st_out[(size_t)m * 2 + 1] = s2; }
 }
 
 template <int BM, int BN, int NS>
@@ -406,6 +492,10 @@ int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
   if (p.nkb <= 0 || p.M <= 0 || p.N <= 0) { dtp_set_error("gemm: empty problem"); return DTP_ERR_ARG; }
   if ((p.lda & 7) || (p.ldw & 7)) { dtp_set_error("gemm: lda/ldw must be multiples of 8"); return DTP_ERR_ARG; }
   if ((p.flags & GF_CONV3) && (p.Cin & 7)) { dtp_set_error("conv: Cin must be a multiple of 8"); return DTP_ERR_ARG; }
+  if ((p.flags & GF_ROWSTATS) && (!p.st_out || (p.flags & (GF_GEGLU | GF_OUT_F32)))) {
+    dtp_set_error("gemm: row statistics need st_out and an fp16, non-GEGLU output");
+    return DTP_ERR_ARG;
+  }
   if ((p.flags & GF_LNFOLD) && (p.splits > 1 || (p.flags & GF_CONV3) || !p.lns)) {
     dtp_set_error("gemm: LayerNorm fold needs a dense, unsplit GEMM with lns");
     return DTP_ERR_ARG;
@@ -430,6 +520,14 @@ int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
 }
 
 int dtp_launch_splitk_reduce(const GemmParams& p, hipStream_t s) {
+  if (p.flags & GF_ROWSTATS) {
+    if (p.flags & (GF_BIAS_M | GF_GELU | GF_QUICKGELU | GF_SILU | GF_OUT_F32 | GF_LNFOLD)) {
+      dtp_set_error("gemm: split-K row statistics support bias/residual epilogues only");
+      return DTP_ERR_ARG;
+    }
+    hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3((p.M + 3) / 4), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+  }
   long long total = (long long)p.M * p.N;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;

@@ -159,27 +159,35 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
   const int C = x.C, S = x.H * x.W, N = x.B;
   T t, y, n1, qkv, a, y2, n2, q2, a2, y3, n3, f, y4;
   RC(b.gn(x, w.gn, 1e-6f, false, t));
-  RC(b.linear(t, w.proj_in, nullptr, 0, y));
+  // LayerNorms are folded into their consumer GEMMs; the row statistics ride on the producer's epilogue
+  RowStats st1, st2, st3;
+  RC(b.alloc_stats(x.rows(), C, st1));
+  RC(b.linear(t, w.proj_in, nullptr, 0, y, &st1));
   b.release(t);
-  RC(b.linear(y, w.qkv, nullptr, 0, qkv));  // LN1 folded
+  RC(b.linear(y, w.qkv, nullptr, 0, qkv, nullptr, &st1));  // LN1 folded
+  b.release_stats(st1);
   T q = qkv, k = qkv, v = qkv;
   q.C = k.C = v.C = C;
   k.p += C; v.p += 2 * C;
   RC(b.attention(q, k, v, 8, S, S, N, a));
   b.release(qkv);
   a.B = x.B; a.H = x.H; a.W = x.W;
-  RC(b.linear(a, w.out1, &y, 0, y2));
+  RC(b.alloc_stats(x.rows(), C, st2));
+  RC(b.linear(a, w.out1, &y, 0, y2, &st2));
   b.release(a); b.release(y);
-  RC(b.linear(y2, w.q2, nullptr, 0, q2));  // LN2 folded
+  RC(b.linear(y2, w.q2, nullptr, 0, q2, nullptr, &st2));  // LN2 folded
+  b.release_stats(st2);
   T kk, vv;
   kk.p = up.kvbuf[w.kv_index]; kk.B = N; kk.H = 1; kk.W = 14; kk.C = C; kk.ld = 2 * C;
   vv = kk; vv.p += C;
   RC(b.attention(q2, kk, vv, 8, S, 14, N, a2));
   b.release(q2);
   a2.B = x.B; a2.H = x.H; a2.W = x.W;
-  RC(b.linear(a2, w.out2, &y2, 0, y3));
+  RC(b.alloc_stats(x.rows(), C, st3));
+  RC(b.linear(a2, w.out2, &y2, 0, y3, &st3));
   b.release(a2); b.release(y2);
-  RC(b.linear(y3, w.ff1, nullptr, GF_GEGLU, f));  // LN3 folded
+  RC(b.linear(y3, w.ff1, nullptr, GF_GEGLU, f, nullptr, &st3));  // LN3 folded
+  b.release_stats(st3);
   RC(b.linear(f, w.ff2, &y3, 0, y4));
   b.release(f); b.release(y3);
   RC(b.linear(y4, w.proj_out, &x, 0, out));
