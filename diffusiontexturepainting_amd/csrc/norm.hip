@@ -187,13 +187,14 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const f16* __restrict__ x
     const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
     const int g1 = g0 + 1 < G ? g0 + 1 : g0;
     const float m0 = st[2 * g0], r0 = st[2 * g0 + 1], m1 = st[2 * g1], r1 = st[2 * g1 + 1];
-    const float* ga = gamma + cs + c0;
-    const float* be = beta + cs + c0;
+    const f32x4 ga0 = *(const f32x4*)(gamma + cs + c0), ga1 = *(const f32x4*)(gamma + cs + c0 + 4);
+    const f32x4 be0 = *(const f32x4*)(beta + cs + c0), be1 = *(const f32x4*)(beta + cs + c0 + 4);
     f16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const bool first = e < split;
-      float f = ((float)v[e] - (first ? m0 : m1)) * (first ? r0 : r1) * ga[e] + be[e];
+      const float gm = e < 4 ? ga0[e] : ga1[e - 4], bt = e < 4 ? be0[e] : be1[e - 4];
+      float f = ((float)v[e] - (first ? m0 : m1)) * (first ? r0 : r1) * gm + bt;
       if (silu) f = f / (1.0f + __expf(-f));
       o[e] = (f16)f;
     }
