@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <unistd.h>
 #include <string.h>
 
 #include <algorithm>
@@ -291,7 +292,8 @@ void tune_cache_load(Ctx* c) {
   if (!f) return;
   char key[256];
   int tile, splits;
-  while (fscanf(f, "%255s %d %d", key, &tile, &splits) == 3) c->tuned[key] = std::make_pair(tile, splits);
+  while (fscanf(f, "%255s %d %d", key, &tile, &splits) == 3)
+    if (tile >= 0 && tile < 12 && splits >= 1 && splits <= 64) c->tuned[key] = std::make_pair(tile, splits);
   fclose(f);
   c->tune_saved = c->tuned.size();
 }
@@ -299,10 +301,13 @@ void tune_cache_load(Ctx* c) {
 void tune_cache_save(Ctx* c) {
   if (c->tune_thrash) { (void)hipDeviceSynchronize(); (void)hipFree(c->tune_thrash); c->tune_thrash = nullptr; }
   if (c->tune_cache_path.empty() || c->tuned.size() == c->tune_saved) return;
-  FILE* f = fopen(c->tune_cache_path.c_str(), "w");
+  // several ranks may share the path: write a private file and rename it into place (atomic)
+  const std::string tmp = c->tune_cache_path + ".tmp." + std::to_string((long long)getpid());
+  FILE* f = fopen(tmp.c_str(), "w");
   if (!f) return;
   for (auto& kv : c->tuned) fprintf(f, "%s %d %d\n", kv.first.c_str(), kv.second.first, kv.second.second);
   fclose(f);
+  (void)rename(tmp.c_str(), c->tune_cache_path.c_str());
   c->tune_saved = c->tuned.size();
 }
 

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
   for (int i = 0; i < WR; ++i) w_row[i] = p.W + (size_t)(n0 + i * 32 + lrow) * p.ldw + kc;
 
-  int tap = 0, cch = 0;  // conv: current tap and channel offset of this thread's chunk
+  int tap = 0, cch = 0, cur_tap = -1;  // conv: current tap / channel offset of this thread's chunk; tap cached in a_row[]
   if (conv) {
     const int k = kb0 * 64 + kc;
     tap = k / p.Cin;
@@ -99,14 +99,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     char* As = smem + stage * STAGE;
     char* Ws = As + BM * 128;
     if (conv) {
-      const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+      // The tap (ky,kx) only changes every Cin/64 k-blocks: the per-row bounds test and pixel address are
+      // recomputed then and cached in a_row[]; in between only the channel offset advances.
+      if (tap != cur_tap) {
+        cur_tap = tap;
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
 #pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-        const bool ok = (tap < 9) && ((unsigned)iy < (unsigned)Hlim) && ((unsigned)ix < (unsigned)Wlim);
-        const f16* src = ok ? p.A + ((size_t)(a_pix[i] + (iy >> ups) * p.Wi + (ix >> ups)) * p.lda + cch) : p.zero;
-        glds16(src, As + (i * 32 + wave * 8) * 128);
+        for (int i = 0; i < AR; ++i) {
+          const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+          const bool ok = (tap < 9) && ((unsigned)iy < (unsigned)Hlim) && ((unsigned)ix < (unsigned)Wlim);
+          a_row[i] = ok ? p.A + (size_t)(a_pix[i] + (iy >> ups) * p.Wi + (ix >> ups)) * p.lda : nullptr;
+        }
       }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) glds16(a_row[i] ? a_row[i] + cch : p.zero, As + (i * 32 + wave * 8) * 128);
       cch += 64;
       while (cch >= p.Cin) { cch -= p.Cin; ++tap; }
     } else {
