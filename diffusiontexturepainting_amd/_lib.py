@@ -35,7 +35,8 @@ class GemmDesc(C.Structure):
                 ("lda", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int),
                 ("conv", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Cin", C.c_int),
                 ("stride", C.c_int), ("pad", C.c_int), ("upsample2x", C.c_int),
-                ("flags", C.c_int), ("tile", C.c_int), ("splits", C.c_int), ("lns", C.c_void_p), ("ln_eps", C.c_float)]
+                ("flags", C.c_int), ("tile", C.c_int), ("splits", C.c_int), ("lns", C.c_void_p), ("ln_eps", C.c_float),
+                ("A2", C.c_void_p), ("lda2", C.c_int), ("Cin2", C.c_int)]
 
 
 GF_BIAS, GF_BIAS_M, GF_RESID, GF_GEGLU, GF_GELU, GF_QUICKGELU, GF_OUT_F32, GF_SILU, GF_LNFOLD = 1, 2, 4, 8, 64, 128, 256, 512, 1024

@@ -72,6 +72,7 @@ int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s) {
   p.Hi = d->Hi; p.Wi = d->Wi; p.Ho = d->Ho; p.Wo = d->Wo; p.Cin = d->Cin; p.stride = d->stride; p.pad = d->pad;
   p.flags = d->flags | (d->conv ? GF_CONV3 : 0) | (d->upsample2x ? GF_UPS2 : 0);
   p.lns = d->lns; p.ln_eps = d->ln_eps;
+  p.A2 = (const f16*)d->A2; p.lda2 = d->lda2; p.Cin2 = d->Cin2;
   if (p.ldw < p.nkb * 64) { dtp_set_error("gemm: ldw=%d smaller than padded K=%d", p.ldw, p.nkb * 64); return DTP_ERR_ARG; }
   int tile = 0;
   dtp_gemm_pick(p, &tile, g_ops.num_cu);

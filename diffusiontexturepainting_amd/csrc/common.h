@@ -64,6 +64,8 @@ struct GemmParams {
   int splits;        // grid.z
   int kb_per_split;
   int Hi, Wi, Ho, Wo, Cin, stride, pad;  // CONV3 geometry (Hi/Wi are the stored input dims)
+  const f16* A2;     // CONV3 only: a 10th, dense "tap" appended to K -- the ResBlock's 1x1 shortcut conv, read from the
+  int lda2, Cin2;    // block input [M][lda2] (Cin2 channels, multiple of 64); null / 0 = none
   int flags;
 };
 

@@ -27,6 +27,7 @@ struct ConvW {  // 3x3 (taps = 9) or 1x1 (taps = 1) convolution / any Linear (ta
   float* b = nullptr;  // fp32 bias (may be null)
   float* lns = nullptr;  // LayerNorm folded in: row sums of the packed weights (GF_LNFOLD)
   int cout = 0, cin = 0 /* padded */, cin_true = 0, taps = 1, K = 0, ldw = 0;
+  int cin2 = 0;  // >0: a 1x1 shortcut conv over cin2 channels is fused as a 10th tap (K = 9*cin + cin2)
 };
 struct NormW {
   float *g = nullptr, *b = nullptr;
@@ -217,6 +218,8 @@ int ctx_upload_f32(Ctx* c, const std::vector<float>& v, float** out);
 int load_norm(Ctx* c, const std::string& name, NormW& n);
 // conv weight [Cout][Cin][k][k] -> packed; cin_pad = padded input channels (>= Cin, multiple of 8)
 int load_conv(Ctx* c, const std::string& name, ConvW& w, int cin_pad = 0, bool bias = true);
+// ResBlock tail: conv2 (3x3) and the 1x1 shortcut conv packed as ONE contraction [W2 | Wsc], bias = b2 + bsc
+int load_conv_with_shortcut(Ctx* c, const std::string& conv, const std::string& shortcut, ConvW& w);
 // stacked linear: rows of several [n_i][K] matrices one after another; geglu packs the [a|gate] tile order
 int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bias, bool geglu = false,
                 const std::string& fold_ln = std::string());  // fold_ln: name of the LayerNorm feeding this Linear
@@ -240,7 +243,7 @@ struct Builder {
   int ln(const T& x, const NormW& n, T& y);
   // conv3x3; bias_step_off >= 0 selects the per-step bias slice from the temb table instead of w.b
   int conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, int Ho, int Wo, const T* resid, int bias_step_off,
-            T& y, int extra_flags = 0, void* out_override = nullptr, int ldc_override = 0);
+            T& y, int extra_flags = 0, void* out_override = nullptr, int ldc_override = 0, const T* tail = nullptr);
   int linear(const T& x, const ConvW& w, const T* resid, int flags, T& y, RowStats* emit = nullptr, const RowStats* use = nullptr);
   int alloc_stats(long long rows, int C, RowStats& st);  // room for one partial per 64-column tile
   void release_stats(RowStats& st);

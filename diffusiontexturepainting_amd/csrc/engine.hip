@@ -125,6 +125,27 @@ int load_conv(Ctx* c, const std::string& name, ConvW& w, int cin_pad, bool bias)
   return DTP_OK;
 }
 
+int load_conv_with_shortcut(Ctx* c, const std::string& conv, const std::string& shortcut, ConvW& w) {
+  const Staged *s = ctx_find(c, conv + ".weight"), *t = ctx_find(c, shortcut + ".weight");
+  const Staged *sb = ctx_find(c, conv + ".bias"), *tb = ctx_find(c, shortcut + ".bias");
+  if (!s || !t || !sb || !tb) { dtp_set_error("missing tensors for '%s' + '%s'", conv.c_str(), shortcut.c_str()); return DTP_ERR_MISSING; }
+  const int cout = (int)s->shape[0], cin = (int)s->shape[1], cin2 = (int)t->shape[1];
+  if ((int)t->shape[0] != cout || ((9 * cin) & 63) || (cin2 & 63)) { dtp_set_error("shortcut fusion: unsupported shape at '%s'", conv.c_str()); return DTP_ERR_ARG; }
+  w.cout = cout; w.cin = cin; w.cin_true = cin; w.taps = 9; w.cin2 = cin2;
+  w.K = 9 * cin + cin2; w.ldw = (int)up_to(w.K, 64);
+  void* p;
+  RC(ctx_arena_alloc(c, up_to(cout, 128) * (size_t)w.ldw * 2, &p));
+  w.w = (f16*)p;
+  RC(dtp_launch_pack_conv_weight(s->d, w.w, cout, cin, cin, 9, w.ldw, 0));
+  RC(dtp_launch_pack_conv_weight(t->d, w.w + 9 * cin, cout, cin2, cin2, 1, w.ldw, 0));
+  std::vector<float> b1, b2;
+  RC(ctx_fetch_host(c, conv + ".bias", b1));
+  RC(ctx_fetch_host(c, shortcut + ".bias", b2));
+  for (size_t i = 0; i < b1.size(); ++i) b1[i] += b2[i];
+  b1.resize(up_to(b1.size(), 128), 0.f);
+  return ctx_upload_f32(c, b1, &w.b);
+}
+
 int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bias, bool geglu, const std::string& fold_ln) {
   int N = 0, K = -1;
   for (const auto& nm : names) {
@@ -316,8 +337,8 @@ void tune_cache_save(Ctx* c) {
 // with every tile variant x split-K factor on the real buffers and the fastest pair is kept.
 static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   char key[200];
-  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin, p.stride,
-           p.lda, p.ldc, p.ldw, p.st_parts);
+  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin, p.stride,
+           p.lda, p.ldc, p.ldw, p.st_parts, p.Cin2, p.lda2);
   auto it = c->tuned.find(key);
   if (it == c->tuned.end()) {
     if (!c->tune_ev[0]) { HIP_CHECK(hipEventCreate(&c->tune_ev[0])); HIP_CHECK(hipEventCreate(&c->tune_ev[1])); }
@@ -344,8 +365,8 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
         q.zero = c->zero;
         // Time it the way the stamp sees it: weights COLD (1.7 GB of them stream through the 256 MiB
         // Infinity Cache every UNet evaluation), activations warm (just written by the previous kernel).
-        float ms = 0.f;
-        for (int rep = 0; rep < 3; ++rep) {
+        float ms = 1e30f;  // best of 5: a single cold run is noisy (DVFS, thrash write-back still draining)
+        for (int rep = 0; rep < 5; ++rep) {
           HIP_CHECK(hipMemsetAsync(c->tune_thrash, rep, THRASH_BYTES, 0));
           RC(dtp_launch_touch(q.A, a_bytes, (float*)c->tune_thrash, 0));
           if (q.R) RC(dtp_launch_touch(q.R, (size_t)q.M * q.ldr * 2, (float*)c->tune_thrash, 0));
@@ -355,7 +376,7 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
           HIP_CHECK(hipEventSynchronize(c->tune_ev[1]));
           float t = 0.f;
           HIP_CHECK(hipEventElapsedTime(&t, c->tune_ev[0], c->tune_ev[1]));
-          ms += t;
+          ms = std::min(ms, t);
         }
         if (ms < best) { best = ms; bt = tile; bs = sp; }
       }
@@ -397,7 +418,8 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
 }
 
 int Builder::conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, int Ho, int Wo, const T* resid,
-                   int bias_step_off, T& y, int extra_flags, void* out_override, int ldc_override) {
+                   int bias_step_off, T& y, int extra_flags, void* out_override, int ldc_override, const T* tail) {
+  if ((w.cin2 > 0) != (tail != nullptr) || (tail && tail->C != w.cin2)) { dtp_set_error("conv3: shortcut tail mismatch"); return DTP_ERR_ARG; }
   if (x.C != w.cin || w.taps != 9) { dtp_set_error("conv3: channel mismatch %d vs %d", x.C, w.cin); return DTP_ERR_ARG; }
   GemmParams p = {};
   p.A = x.p; p.W = w.w;
@@ -406,6 +428,7 @@ int Builder::conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, in
   p.nkb = w.ldw / 64;
   p.Hi = x.H; p.Wi = x.W; p.Ho = Ho; p.Wo = Wo; p.Cin = w.cin; p.stride = stride; p.pad = pad;
   p.flags = GF_CONV3 | (ups ? GF_UPS2 : 0) | extra_flags;
+  if (tail) { p.A2 = tail->p; p.lda2 = tail->ld; p.Cin2 = w.cin2; }
   if (out_override) {
     y = T();
     y.p = (f16*)out_override; y.B = x.B; y.H = Ho; y.W = Wo; y.C = w.cout; y.ld = ldc_override;
@@ -416,7 +439,7 @@ int Builder::conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, in
   p.C = y.p; p.ldc = y.ld;
   if (w.b || bias_step_off >= 0) { p.flags |= GF_BIAS; p.bias = w.b; }
   if (resid) { p.flags |= GF_RESID; p.R = resid->p; p.ldr = resid->ld; }
-  return push_gemm(c, prog, p, bias_step_off, 9.0 * w.cin_true);
+  return push_gemm(c, prog, p, bias_step_off, 9.0 * w.cin_true + w.cin2);
 }
 
 int Builder::alloc_stats(long long rows, int C, RowStats& st) {
@@ -481,14 +504,12 @@ int Builder::resnet(const T& x, const ResW& w, float eps, bool temb, T& y) {
   release(t1);
   RC(gn(h, w.n2, eps, true, t2));
   release(h);
-  const T* res = &x;
-  if (w.has_sc) {
-    RC(linear(x, w.sc, nullptr, 0, sc));
-    res = &sc;
+  if (w.has_sc) {  // conv2 and the 1x1 shortcut are one contraction: [im2col(t2) | x] . [W2 | Wsc]^T
+    RC(conv3(t2, w.c2, 1, 1, false, x.H, x.W, nullptr, -1, y, 0, nullptr, 0, &x));
+  } else {
+    RC(conv3(t2, w.c2, 1, 1, false, x.H, x.W, &x, -1, y));
   }
-  RC(conv3(t2, w.c2, 1, 1, false, x.H, x.W, res, -1, y));
   release(t2);
-  if (w.has_sc) release(sc);
   return DTP_OK;
 }
 

@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   int tap = 0, cch = 0, cur_tap = -1;  // conv: current tap / channel offset of this thread's chunk; tap cached in a_row[]
   if (conv) {
     const int k = kb0 * 64 + kc;
-    tap = k / p.Cin;
-    cch = k - tap * p.Cin;
+    if (k < 9 * p.Cin) { tap = k / p.Cin; cch = k - tap * p.Cin; }
+    else { tap = 9; cch = k - 9 * p.Cin; }  // inside the fused 1x1-shortcut tail
   }
 
   auto issue = [&](int stage, int kb) {
@@ -103,18 +103,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       // recomputed then and cached in a_row[]; in between only the channel offset advances.
       if (tap != cur_tap) {
         cur_tap = tap;
-        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        if (tap < 9) {
+          const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-          const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-          const bool ok = (tap < 9) && ((unsigned)iy < (unsigned)Hlim) && ((unsigned)ix < (unsigned)Wlim);
-          a_row[i] = ok ? p.A + (size_t)(a_pix[i] + (iy >> ups) * p.Wi + (ix >> ups)) * p.lda : nullptr;
+          for (int i = 0; i < AR; ++i) {
+            const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+            const bool ok = ((unsigned)iy < (unsigned)Hlim) && ((unsigned)ix < (unsigned)Wlim);
+            a_row[i] = ok ? p.A + (size_t)(a_pix[i] + (iy >> ups) * p.Wi + (ix >> ups)) * p.lda : nullptr;
+          }
+        } else {  // dense tail: output pixel m reads row m of the shortcut input
+#pragma unroll
+          for (int i = 0; i < AR; ++i) {
+            const int m = m0 + i * 32 + lrow;
+            a_row[i] = (tap == 9 && p.A2 && m < p.M) ? p.A2 + (size_t)m * p.lda2 : nullptr;
+          }
         }
       }
 #pragma unroll
       for (int i = 0; i < AR; ++i) glds16(a_row[i] ? a_row[i] + cch : p.zero, As + (i * 32 + wave * 8) * 128);
       cch += 64;
-      while (cch >= p.Cin) { cch -= p.Cin; ++tap; }
+      if (tap < 9) { while (cch >= p.Cin) { cch -= p.Cin; ++tap; } }
+      else if (cch >= p.Cin2) { cch -= p.Cin2; ++tap; }
     } else {
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
@@ -498,6 +507,10 @@ int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
   if (p.nkb <= 0 || p.M <= 0 || p.N <= 0) { dtp_set_error("gemm: empty problem"); return DTP_ERR_ARG; }
   if ((p.lda & 7) || (p.ldw & 7)) { dtp_set_error("gemm: lda/ldw must be multiples of 8"); return DTP_ERR_ARG; }
   if ((p.flags & GF_CONV3) && (p.Cin & 7)) { dtp_set_error("conv: Cin must be a multiple of 8"); return DTP_ERR_ARG; }
+  if (p.A2 && (!(p.flags & GF_CONV3) || ((9 * p.Cin) & 63) || (p.Cin2 & 63) || (p.lda2 & 7) || p.stride != 1)) {
+    dtp_set_error("conv: fused shortcut tail needs stride 1 and 9*Cin, Cin2 multiples of 64");
+    return DTP_ERR_ARG;
+  }
   if ((p.flags & GF_ROWSTATS) && (!p.st_out || (p.flags & (GF_GEGLU | GF_OUT_F32)))) {
     dtp_set_error("gemm: row statistics need st_out and an fp16, non-GEGLU output");
     return DTP_ERR_ARG;

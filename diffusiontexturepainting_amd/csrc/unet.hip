@@ -12,9 +12,9 @@ static int load_res(Ctx* c, const std::string& p, ResW& w, bool temb, int& temb_
   RC(load_norm(c, p + ".norm1", w.n1));
   RC(load_conv(c, p + ".conv1", w.c1));
   RC(load_norm(c, p + ".norm2", w.n2));
-  RC(load_conv(c, p + ".conv2", w.c2));
   w.has_sc = ctx_find(c, p + ".conv_shortcut.weight") != nullptr;
-  if (w.has_sc) RC(load_conv(c, p + ".conv_shortcut", w.sc));
+  if (w.has_sc) RC(load_conv_with_shortcut(c, p + ".conv2", p + ".conv_shortcut", w.c2));
+  else RC(load_conv(c, p + ".conv2", w.c2));
   if (temb) {
     w.temb_off = temb_off_acc;
     temb_off_acc += w.c1.cout;

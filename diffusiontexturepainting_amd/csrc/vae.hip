@@ -11,9 +11,9 @@ static int load_res_v(Ctx* c, const std::string& p, ResW& w) {
   RC(load_norm(c, p + ".norm1", w.n1));
   RC(load_conv(c, p + ".conv1", w.c1));
   RC(load_norm(c, p + ".norm2", w.n2));
-  RC(load_conv(c, p + ".conv2", w.c2));
   w.has_sc = ctx_find(c, p + ".conv_shortcut.weight") != nullptr;
-  if (w.has_sc) RC(load_conv(c, p + ".conv_shortcut", w.sc));
+  if (w.has_sc) RC(load_conv_with_shortcut(c, p + ".conv2", p + ".conv_shortcut", w.c2));
+  else RC(load_conv(c, p + ".conv2", w.c2));
   return DTP_OK;
 }
 

@@ -73,7 +73,8 @@ def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, ou
     return out
 
 
-def conv3x3(x, wp, cout, stride=1, pad=1, upsample=False, bias=None, resid=None, tile=-1, splits=0, out_hw=None, flags=0):
+def conv3x3(x, wp, cout, stride=1, pad=1, upsample=False, bias=None, resid=None, tile=-1, splits=0, out_hw=None, flags=0,
+            tail=None):
     """x f16 NHWC [B,H,W,C] -> f16 NHWC [B,Ho,Wo,cout].  pad is the top/left zero padding; bottom/right
     padding is implied by out_hw (default: the symmetric-padding output size)."""
     lib = _lib.load()
@@ -85,7 +86,9 @@ def conv3x3(x, wp, cout, stride=1, pad=1, upsample=False, bias=None, resid=None,
     d.A, d.W, d.C = x.data_ptr(), wp.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.R = resid.data_ptr() if resid is not None else None
-    d.M, d.N, d.K = b * ho * wo, cout, 9 * cin
+    d.M, d.N, d.K = b * ho * wo, cout, 9 * cin + (tail.shape[-1] if tail is not None else 0)
+    if tail is not None:  # fused 1x1 shortcut: NHWC tensor with the output's spatial size
+        d.A2, d.lda2, d.Cin2 = tail.data_ptr(), tail.stride(2), tail.shape[-1]
     d.lda, d.ldw, d.ldc = x.stride(2), wp.stride(0), cout
     d.ldr = resid.stride(2) if resid is not None else 0
     d.conv, d.Hi, d.Wi, d.Ho, d.Wo, d.Cin, d.stride, d.pad, d.upsample2x = 1, h, w, ho, wo, cin, stride, pad, int(upsample)

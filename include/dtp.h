@@ -135,6 +135,8 @@ typedef struct {
   int splits;        /* 0 = heuristic; >=1 = forced split-K factor */
   const float* lns;  /* DTP_GF_LNFOLD: row sums of the packed weights (dtp_op_rowsum) */
   float ln_eps;
+  const void* A2;    /* conv only: fused 1x1-shortcut tail, f16 [M][lda2] with Cin2 channels appended to K (W = [W3x3 | W1x1]) */
+  int lda2, Cin2;
 } dtp_gemm_desc;
 enum { DTP_GF_BIAS = 1, DTP_GF_BIAS_M = 2, DTP_GF_RESID = 4, DTP_GF_GEGLU = 8, DTP_GF_GELU = 64, DTP_GF_QUICKGELU = 128,
        DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512, DTP_GF_LNFOLD = 1024 };

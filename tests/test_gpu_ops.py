@@ -170,6 +170,19 @@ def test_conv3x3(ops, case, tile):
     close(got, ref)
 
 
+@pytest.mark.parametrize("b,h,cin,cin2,cout,tile,splits", [(2, 16, 64, 128, 64, -1, 0), (3, 8, 320, 640, 320, 5, 0), (1, 8, 128, 64, 256, 8, 3)])
+def test_conv3x3_fused_shortcut(ops, b, h, cin, cin2, cout, tile, splits):
+    """ResBlock tail as ONE contraction: conv3x3(t) + conv1x1(x) + biases = [im2col(t) | x] . [W3 | W1]^T."""
+    t, x = rnd(b, h, h, cin, seed=24), rnd(b, h, h, cin2, seed=25)
+    w3 = rnd(cout, cin, 3, 3, seed=26, scale=(9 * cin) ** -0.5)
+    w1 = rnd(cout, cin2, 1, 1, seed=27, scale=cin2 ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(28))
+    ref = F.conv2d(t.float().permute(0, 3, 1, 2), w3.float(), bias, padding=1) + F.conv2d(x.float().permute(0, 3, 1, 2), w1.float())
+    wp = torch.cat([ops.pack_conv(w3.float().cuda())[:, : 9 * cin], ops.pack_conv(w1.float().cuda())[:, :cin2]], dim=1).contiguous()
+    got = ops.conv3x3(t.cuda(), wp, cout, bias=bias.cuda(), tail=x.cuda(), tile=tile, splits=splits)
+    close(got, ref.permute(0, 2, 3, 1))
+
+
 def test_conv3x3_strided_view_and_f32_out(ops):
     """Input is a channel slice of a wider NHWC buffer (lda > Cin); output fp32."""
     from diffusiontexturepainting_amd._lib import GF_OUT_F32
