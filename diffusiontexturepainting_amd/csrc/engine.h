@@ -243,13 +243,15 @@ struct Builder {
   int ln(const T& x, const NormW& n, T& y);
   // conv3x3; bias_step_off >= 0 selects the per-step bias slice from the temb table instead of w.b
   int conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, int Ho, int Wo, const T* resid, int bias_step_off,
-            T& y, int extra_flags = 0, void* out_override = nullptr, int ldc_override = 0, const T* tail = nullptr);
-  int linear(const T& x, const ConvW& w, const T* resid, int flags, T& y, RowStats* emit = nullptr, const RowStats* use = nullptr);
+            T& y, int extra_flags = 0, void* out_override = nullptr, int ldc_override = 0, const T* tail = nullptr,
+            const T* dst = nullptr);  // dst: write into this (possibly strided) view instead of a fresh buffer
+  int linear(const T& x, const ConvW& w, const T* resid, int flags, T& y, RowStats* emit = nullptr, const RowStats* use = nullptr,
+             const T* dst = nullptr);
   int alloc_stats(long long rows, int C, RowStats& st);  // room for one partial per 64-column tile
   void release_stats(RowStats& st);
   int attention(const T& q, const T& k, const T& v, int heads, int Sq, int Skv, int Bn, T& o);
   int concat(const T& a, const T& b, T& y);
-  int resnet(const T& x, const ResW& w, float eps, bool temb, T& y);
+  int resnet(const T& x, const ResW& w, float eps, bool temb, T& y, const T* dst = nullptr);
 };
 
 int build_unet_prog(Ctx* c, int N, UNetProg& up);

@@ -418,7 +418,7 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
 }
 
 int Builder::conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, int Ho, int Wo, const T* resid,
-                   int bias_step_off, T& y, int extra_flags, void* out_override, int ldc_override, const T* tail) {
+                   int bias_step_off, T& y, int extra_flags, void* out_override, int ldc_override, const T* tail, const T* dst) {
   if ((w.cin2 > 0) != (tail != nullptr) || (tail && tail->C != w.cin2)) { dtp_set_error("conv3: shortcut tail mismatch"); return DTP_ERR_ARG; }
   if (x.C != w.cin || w.taps != 9) { dtp_set_error("conv3: channel mismatch %d vs %d", x.C, w.cin); return DTP_ERR_ARG; }
   GemmParams p = {};
@@ -432,6 +432,9 @@ int Builder::conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, in
   if (out_override) {
     y = T();
     y.p = (f16*)out_override; y.B = x.B; y.H = Ho; y.W = Wo; y.C = w.cout; y.ld = ldc_override;
+  } else if (dst) {
+    if (dst->C != w.cout || dst->rows() != (long long)x.B * Ho * Wo) { dtp_set_error("conv3: destination view mismatch"); return DTP_ERR_ARG; }
+    y = *dst;
   } else {
     y = alloc(x.B, Ho, Wo, w.cout);
     if (!y.p) return DTP_ERR_HIP;
@@ -452,15 +455,20 @@ int Builder::alloc_stats(long long rows, int C, RowStats& st) {
 }
 void Builder::release_stats(RowStats& st) { ctx_pool_put(c, st.buf); st.buf = nullptr; }
 
-int Builder::linear(const T& x, const ConvW& w, const T* resid, int flags, T& y, RowStats* emit, const RowStats* use) {
+int Builder::linear(const T& x, const ConvW& w, const T* resid, int flags, T& y, RowStats* emit, const RowStats* use, const T* dst) {
   if (x.C != w.K || w.taps != 1) { dtp_set_error("linear: K mismatch %d vs %d", x.C, w.K); return DTP_ERR_ARG; }
   GemmParams p = {};
   p.A = x.p; p.W = w.w;
   p.M = (int)x.rows(); p.N = w.cout; p.K = w.K;
   p.lda = x.ld; p.ldw = w.ldw; p.nkb = w.ldw / 64;
   p.flags = flags;
-  y = alloc(x.B, x.H, x.W, (flags & GF_GEGLU) ? w.cout / 2 : w.cout);
-  if (!y.p) return DTP_ERR_HIP;
+  if (dst) {
+    if (dst->C != w.cout || (flags & GF_GEGLU) || dst->rows() != x.rows()) { dtp_set_error("linear: destination view mismatch"); return DTP_ERR_ARG; }
+    y = *dst;
+  } else {
+    y = alloc(x.B, x.H, x.W, (flags & GF_GEGLU) ? w.cout / 2 : w.cout);
+    if (!y.p) return DTP_ERR_HIP;
+  }
   p.C = y.p; p.ldc = y.ld;
   if (w.b) { p.flags |= GF_BIAS; p.bias = w.b; }
   if (w.lns) {  // x is the raw pre-LayerNorm tensor
@@ -497,7 +505,7 @@ int Builder::concat(const T& a, const T& b, T& y) {
   return DTP_OK;
 }
 
-int Builder::resnet(const T& x, const ResW& w, float eps, bool temb, T& y) {
+int Builder::resnet(const T& x, const ResW& w, float eps, bool temb, T& y, const T* dst) {
   T t1, h, t2, sc;
   RC(gn(x, w.n1, eps, true, t1));
   RC(conv3(t1, w.c1, 1, 1, false, x.H, x.W, nullptr, temb ? w.temb_off : -1, h));
@@ -505,9 +513,9 @@ int Builder::resnet(const T& x, const ResW& w, float eps, bool temb, T& y) {
   RC(gn(h, w.n2, eps, true, t2));
   release(h);
   if (w.has_sc) {  // conv2 and the 1x1 shortcut are one contraction: [im2col(t2) | x] . [W2 | Wsc]^T
-    RC(conv3(t2, w.c2, 1, 1, false, x.H, x.W, nullptr, -1, y, 0, nullptr, 0, &x));
+    RC(conv3(t2, w.c2, 1, 1, false, x.H, x.W, nullptr, -1, y, 0, nullptr, 0, &x, dst));
   } else {
-    RC(conv3(t2, w.c2, 1, 1, false, x.H, x.W, &x, -1, y));
+    RC(conv3(t2, w.c2, 1, 1, false, x.H, x.W, &x, -1, y, 0, nullptr, 0, nullptr, dst));
   }
   release(t2);
   return DTP_OK;

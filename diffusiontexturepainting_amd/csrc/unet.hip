@@ -155,7 +155,7 @@ int ensure_temb(Ctx* c, const std::vector<float>& timesteps) {
   return DTP_OK;
 }
 
-static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up, T& out) {
+static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up, T& out, const T* dst = nullptr) {
   const int C = x.C, S = x.H * x.W, N = x.B;
   T t, y, n1, qkv, a, y2, n2, q2, a2, y3, n3, f, y4;
   RC(b.gn(x, w.gn, 1e-6f, false, t));
@@ -190,7 +190,7 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
   b.release_stats(st3);
   RC(b.linear(f, w.ff2, &y3, 0, y4));
   b.release(f); b.release(y3);
-  RC(b.linear(y4, w.proj_out, &x, 0, out));
+  RC(b.linear(y4, w.proj_out, &x, 0, out, nullptr, nullptr, dst));
   b.release(y4);
   return DTP_OK;
 }
@@ -229,60 +229,74 @@ int build_unet_prog(Ctx* c, int N, UNetProg& up) {
   Builder b{c, &up.main};
   T x0;
   x0.p = up.in16; x0.B = N; x0.H = h; x0.W = h; x0.C = 16; x0.ld = 16;
+  // Zero-copy skip connections: every up-path ResBlock consumes cat([x, skip], C).  The 12 concat buffers are
+  // planned up front; the skip's producer (down path) writes channels [Cx, Cx+Cs) and the x producer (up path)
+  // writes channels [0, Cx) of the same buffer through the row stride, so no concat kernel ever runs.
+  const int Cs[12] = {320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280};   // skip k, in push order
+  const int Cx[12] = {1280, 1280, 1280, 1280, 1280, 1280, 1280, 640, 640, 640, 320, 320};  // x at up position p = 11-k
+  const int Hs[12] = {h, h, h, h / 2, h / 2, h / 2, h / 4, h / 4, h / 4, h / 8, h / 8, h / 8};
+  T cat[12], skipv[12], xslot[12];
+  for (int k = 0; k < 12; ++k) {
+    const int cx = Cx[11 - k];
+    cat[k] = b.alloc(N, Hs[k], Hs[k], cx + Cs[k]);
+    if (!cat[k].p) return DTP_ERR_HIP;
+    skipv[k] = cat[k]; skipv[k].p += cx; skipv[k].C = Cs[k];
+    xslot[k] = cat[k]; xslot[k].C = cx;
+  }
+  int sk = 0;  // next skip to produce
   T x;
-  RC(b.conv3(x0, u.conv_in, 1, 1, false, h, h, nullptr, -1, x));
-  std::vector<T> skips;
-  skips.push_back(x);
+  RC(b.conv3(x0, u.conv_in, 1, 1, false, h, h, nullptr, -1, x, 0, nullptr, 0, nullptr, &skipv[sk++]));
   for (int i = 0; i < 4; ++i) {
     for (int j = 0; j < 2; ++j) {
       T y;
-      RC(b.resnet(x, u.down_res[i][j], 1e-5f, true, y));
-      // x stays alive as a skip (it was pushed) -- do not release
-      x = y;
       if (i < 3) {
+        RC(b.resnet(x, u.down_res[i][j], 1e-5f, true, y));
         T z;
-        RC(transformer(b, x, u.down_xf[i][j], up, z));
-        b.release(x);
+        RC(transformer(b, y, u.down_xf[i][j], up, z, &skipv[sk++]));
+        b.release(y);
         x = z;
+      } else {
+        RC(b.resnet(x, u.down_res[i][j], 1e-5f, true, y, &skipv[sk++]));
+        x = y;
       }
-      skips.push_back(x);
     }
     if (i < 3) {
       T y;
-      RC(b.conv3(x, u.down_conv[i], 2, 1, false, x.H / 2, x.W / 2, nullptr, -1, y));
+      RC(b.conv3(x, u.down_conv[i], 2, 1, false, x.H / 2, x.W / 2, nullptr, -1, y, 0, nullptr, 0, nullptr, &skipv[sk++]));
       x = y;
-      skips.push_back(x);
     }
   }
+  int pk = 11;  // concat buffer consumed next
   {
     T y, z, w2;
-    RC(b.resnet(x, u.mid_res[0], 1e-5f, true, y));  // x is skips.back(): keep
+    RC(b.resnet(x, u.mid_res[0], 1e-5f, true, y));  // x is a skip view: stays alive
     RC(transformer(b, y, u.mid_xf, up, z));
     b.release(y);
-    RC(b.resnet(z, u.mid_res[1], 1e-5f, true, w2));
+    RC(b.resnet(z, u.mid_res[1], 1e-5f, true, w2, &xslot[pk]));
     b.release(z);
-    x = w2;
   }
   for (int i = 0; i < 4; ++i) {
     for (int j = 0; j < 3; ++j) {
-      T skip = skips.back();
-      skips.pop_back();
-      T cat, y;
-      RC(b.concat(x, skip, cat));
-      b.release(x); b.release(skip);
-      RC(b.resnet(cat, u.up_res[i][j], 1e-5f, true, y));
-      b.release(cat);
-      x = y;
+      const T in = cat[pk];
+      // where this layer's output goes: the x slot of the next concat buffer, unless an upsampler (or the end) follows
+      const T* dst = (j < 2) ? &xslot[pk - 1] : nullptr;
+      T y;
       if (i > 0) {
+        RC(b.resnet(in, u.up_res[i][j], 1e-5f, true, y));
         T z;
-        RC(transformer(b, x, u.up_xf[i][j], up, z));
-        b.release(x);
+        RC(transformer(b, y, u.up_xf[i][j], up, z, dst));
+        b.release(y);
         x = z;
+      } else {
+        RC(b.resnet(in, u.up_res[i][j], 1e-5f, true, y, dst));
+        x = y;
       }
+      b.release(in);
+      --pk;
     }
     if (i < 3) {
       T y;
-      RC(b.conv3(x, u.up_conv[i], 1, 1, true, x.H * 2, x.W * 2, nullptr, -1, y));
+      RC(b.conv3(x, u.up_conv[i], 1, 1, true, x.H * 2, x.W * 2, nullptr, -1, y, 0, nullptr, 0, nullptr, &xslot[pk]));
       b.release(x);
       x = y;
     }
