@@ -310,7 +310,7 @@ int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* ga
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(threads), 0, s, x, ldx, ws, HW, C, cpg, groups, ppc);
   const long long per_batch = (long long)HW * nch;
   long long bx = (per_batch + 255) / 256;
-  const long long cap = std::max<long long>(1, 768 / B);  // every block re-reduces the partials of its batch item
+  const long long cap = std::max<long long>(1, 768 / B);  // every block re-reduces the partials of its batch item first
   if (bx > cap) bx = cap;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((int)bx, B), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, ws, nchunk, HW, C, cpg,
                      groups, silu, 1.0f / ((float)HW * cpg), eps);
