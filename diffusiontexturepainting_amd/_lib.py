@@ -26,7 +26,8 @@ class ProfRow(C.Structure):
 _SHAPES = [(128, 128), (128, 64), (64, 64), (64, 128)]
 PROF_KINDS = [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 4}>" for i in range(12)] + \
     ["attention_kernel", "groupnorm (gn_stats+gn_apply | gn_fused)", "layernorm_kernel", "concat_kernel / small elementwise",
-     "softmax_rows_kernel"]
+     "softmax_rows_kernel", "conv_halo_kernel<8, 16, 64>", "conv_halo_kernel<8, 16, 128>", "conv_halo_kernel<8, 8, 64>",
+     "conv_halo_kernel<8, 8, 128>"]
 
 
 class GemmDesc(C.Structure):
@@ -36,7 +37,7 @@ class GemmDesc(C.Structure):
                 ("conv", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Cin", C.c_int),
                 ("stride", C.c_int), ("pad", C.c_int), ("upsample2x", C.c_int),
                 ("flags", C.c_int), ("tile", C.c_int), ("splits", C.c_int), ("lns", C.c_void_p), ("ln_eps", C.c_float),
-                ("A2", C.c_void_p), ("lda2", C.c_int), ("Cin2", C.c_int)]
+                ("A2", C.c_void_p), ("lda2", C.c_int), ("Cin2", C.c_int), ("Wcb", C.c_void_p)]
 
 
 GF_BIAS, GF_BIAS_M, GF_RESID, GF_GEGLU, GF_GELU, GF_QUICKGELU, GF_OUT_F32, GF_SILU, GF_LNFOLD = 1, 2, 4, 8, 64, 128, 256, 512, 1024
@@ -68,6 +69,7 @@ SYMBOLS = {
     "dtp_op_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dtp_op_pack_conv": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dtp_op_rowsum": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "dtp_op_pack_conv_cb": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "dtp_op_groupnorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "dtp_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
     "dtp_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp]),

@@ -63,6 +63,8 @@ int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s) {
   std::lock_guard<std::mutex> lk(g_ops_mu);
   int rc = ops_init();
   if (rc) return rc;
+  static bool halo_init = false;
+  if (!halo_init) { dtp_conv_halo_init(); halo_init = true; }
   GemmParams p = {};
   p.A = (const f16*)d->A; p.W = (const f16*)d->W; p.C = d->C; p.bias = d->bias; p.R = (const f16*)d->R;
   p.zero = g_ops.zero;
@@ -81,9 +83,17 @@ int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s) {
     p.kb_per_split = (p.nkb + d->splits - 1) / d->splits;
     p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
   }
+  if (tile >= 12) {  // halo-tiled 3x3 conv: split-K counts 64-channel blocks
+    if (!d->Wcb) { dtp_set_error("conv_halo: Wcb missing"); return DTP_ERR_ARG; }
+    p.W = (const f16*)d->Wcb;
+    const int ncb = p.Cin / 64, sp = d->splits >= 1 ? d->splits : 1;
+    p.kb_per_split = (ncb + sp - 1) / sp;
+    p.splits = (ncb + p.kb_per_split - 1) / p.kb_per_split;
+  }
   rc = ops_ws(dtp_gemm_workspace_bytes(p));
   if (rc) return rc;
   p.part = g_ops.ws;
+  if (tile >= 12) return dtp_launch_conv_halo(p, tile - 12, (hipStream_t)s);
   return dtp_launch_gemm(p, tile, (hipStream_t)s);
 }
 
@@ -118,6 +128,10 @@ int dtp_op_rowsum(const void* w, int ld, int K, float* out, int rows, dtp_stream
 
 int dtp_op_pack_conv(const float* w, void* out, int Cout, int Cin, int Cin_pad, int taps, int ldw, dtp_stream s) {
   return dtp_launch_pack_conv_weight(w, (f16*)out, Cout, Cin, Cin_pad, taps, ldw, (hipStream_t)s);
+}
+
+int dtp_op_pack_conv_cb(const float* w, void* out, int Cout, int Cin, int ldw, dtp_stream s) {
+  return dtp_launch_pack_conv_weight_cb(w, (f16*)out, Cout, Cin, ldw, (hipStream_t)s);
 }
 
 int dtp_op_groupnorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,

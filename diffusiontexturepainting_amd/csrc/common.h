@@ -48,6 +48,7 @@ enum {
 struct GemmParams {
   const f16* A;      // activations: dense [M][lda] or NHWC image for CONV3
   const f16* W;      // weights [N_pad][ldw], K contiguous, zero padded to k-block multiples
+  const f16* Wcb;    // same 3x3 weights packed channel-block-major (k' = (cb*9+tap)*64 + c) for conv_halo_kernel; may be null
   void* C;           // fp16 [M][ldc] (or fp32 with GF_OUT_F32)
   float* part;       // split-K partial slabs [splits][M][N] fp32 (when splits > 1)
   const float* bias; // fp32
@@ -106,5 +107,10 @@ int dtp_launch_pack_linear_weight(const float* w, f16* out, int N, int K, int ld
 int dtp_launch_rowdot(const float* w, const float* v, float* out, int N, int K, hipStream_t s);
 int dtp_launch_scale_cols(float* w, const float* g, int N, int K, hipStream_t s);
 int dtp_launch_rowsum_f16(const f16* w, int ld, int K, float* out, int rows, hipStream_t s);
+// conv_halo.hip: variant 0..3 = (8x16|8x8 pixel tile) x (64|128 output channels); kb_per_split counts 64-channel blocks
+bool dtp_conv_halo_supported(const GemmParams& p);
+int dtp_launch_conv_halo(const GemmParams& p, int variant, hipStream_t s);
+void dtp_conv_halo_init();
+int dtp_launch_pack_conv_weight_cb(const float* w, f16* out, int Cout, int Cin, int ldw, hipStream_t s);
 int dtp_launch_touch(const void* p, size_t bytes, float* sink, hipStream_t s);
 int dtp_launch_lora_merge(float* w, const float* up, const float* down, int N, int K, int rank, float scale, hipStream_t s);

@@ -1,0 +1,272 @@
+// Halo-tiled 3x3 convolution for gfx950 (stride 1, pad 1): the LDS-staged im2col of the stamp path.
+//
+// gemm_kernel treats a 3x3 conv as a GEMM whose A operand is re-gathered from L2 for every tap: each input
+// element crosses L2 -> LDS nine times.  Here a workgroup owns a TH x TW patch of output pixels of one image;
+// for every 64-channel block it stages the (TH+2) x (TW+2) input patch (with its zero-padded halo) in LDS ONCE
+// and all nine taps read their shifted rows from it, so the A-side LDS fill traffic drops ~6.4x and the only
+// per-tap DMA is the 64-wide weight slice.  Weights are packed channel-block-major: k' = (cb*9 + tap)*64 + c.
+//
+// Same MFMA mapping, LDS swizzle, epilogue and split-K convention as gemm_kernel (see gemm_conv.hip); the
+// pipeline is: weights in a 3-deep ring (counted vmcnt, raw s_barrier per tap), halo double-buffered and
+// refilled during tap 0 of the previous channel block.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TH, int TW, int BN>
+__global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
+  constexpr int BM = TH * TW;                       // output pixels per workgroup (64 or 128)
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int WR = BN / 32;                       // weight DMA instructions per wave per tap
+  constexpr int HP = (TH + 2) * (TW + 2);           // halo pixels
+  constexpr int HL = (HP + 31) / 32;                // halo DMA instructions per wave per channel block (8 pixels each)
+  constexpr int HROWS = HL * 32;                    // padded halo rows
+  constexpr int HBYTES = HROWS * 128, WBYTES = BN * 128;
+  constexpr int SLD = BN + 8;
+  static_assert(2 * HBYTES + 3 * WBYTES >= BM * SLD * 2, "staging tile must fit");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const halo = smem;                 // [2][HROWS][128]
+  char* const wring = smem + 2 * HBYTES;   // [3][BN][128]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.Hi, W = p.Wi;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, tiles_n = (p.N + BN - 1) / BN;
+  const int nimg = p.M / (H * W);
+  const int nwg = nimg * tiles_y * tiles_x * tiles_n;
+  int wg;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = wg % tiles_n;  // neighbouring workgroups share the input patch
+  int rest = wg / tiles_n;
+  const int tx = rest % tiles_x; rest /= tiles_x;
+  const int ty = rest % tiles_y;
+  const int img = rest / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = tile_n * BN;
+  const int ncb = p.Cin >> 6;                       // 64-channel blocks
+  const int cb0 = blockIdx.z * p.kb_per_split;      // split-K over channel blocks (kb_per_split counts channel blocks here)
+  const int ncbl = min(p.kb_per_split, ncb - cb0);
+  const int nit = ncbl * 9;
+
+  // ---- halo DMA source: instruction i of this wave covers halo rows (i*4 + wave)*8 .. +7; lane -> (row, slot)
+  const int kc8 = lane & 7;
+  const f16* hsrc[HL];
+  int hkc[HL];
+#pragma unroll
+  for (int i = 0; i < HL; ++i) {
+    const int hp = (i * 4 + wave) * 8 + (lane >> 3);
+    const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool ok = (hp < HP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+    hkc[i] = ((kc8 ^ ((hp >> 1) & 7)) << 3);
+    hsrc[i] = ok ? p.A + ((size_t)(img * H + iy) * W + ix) * p.lda + hkc[i] : nullptr;
+  }
+  const int lrow = wave * 8 + (lane >> 3);
+  const int wkc = ((kc8 ^ ((lrow >> 1) & 7)) << 3);
+  const f16* w_row[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) w_row[i] = p.W + (size_t)(n0 + i * 32 + lrow) * p.ldw + wkc;
+
+  auto issue_halo = [&](int buf, int cb) {
+    char* dst = halo + buf * HBYTES;
+#pragma unroll
+    for (int i = 0; i < HL; ++i) glds16(hsrc[i] ? hsrc[i] + (size_t)cb * 64 : p.zero, dst + (i * 4 + wave) * 8 * 128);
+  };
+  auto issue_w = [&](int buf, int it) {  // it = absolute k-block index (cb*9 + tap)
+    char* dst = wring + buf * WBYTES;
+#pragma unroll
+    for (int i = 0; i < WR; ++i) glds16(w_row[i] + (size_t)it * 64, dst + (i * 32 + wave * 8) * 128);
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wn0 = (wave & 1) * (BN / 2), wm0 = (wave >> 1) * (BM / 2);
+  const int frow = lane & 31, fhalf = lane >> 5;
+  int hbase[TM];  // halo row of this lane's output pixel for tap (0,0)
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int r = wm0 + j * 32 + frow;
+    hbase[j] = (r / TW) * (TW + 2) + (r % TW);
+  }
+
+  // ---- prologue: halo(cb0), W(0), W(1)
+  const int it0 = cb0 * 9;
+  if (nit > 0) {
+    issue_halo(0, cb0);
+    issue_w(0, it0);
+    if (nit > 1) issue_w(1, it0 + 1);
+  }
+  int wcur = 0, wnxt = 2, tap = 0, cbl = 0;  // ring slot of W(t) / of W(t+2); tap and local channel block of iteration t
+  for (int t = 0; t < nit; ++t) {
+    // W(t) (and the halo it needs) have landed once only the younger groups of this wave are outstanding:
+    // W(t+1) [+ the halo refill issued at tap 0 of this channel block, which is younger than W(t) only when t-1 had tap 0]
+    if (t + 1 >= nit) wait_vmcnt<0>();
+    else if (tap == 1 && cbl + 1 < ncbl) wait_vmcnt<WR + HL>();
+    else wait_vmcnt<WR>();
+    __builtin_amdgcn_s_barrier();
+    if (tap == 0 && cbl + 1 < ncbl) issue_halo((cbl + 1) & 1, cb0 + cbl + 1);
+    if (t + 2 < nit) issue_w(wnxt, it0 + t + 2);
+    const char* Hs = halo + (cbl & 1) * HBYTES;
+    const char* Ws = wring + wcur * WBYTES;
+    const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+    const int hoff = ky * (TW + 2) + kx;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks * 2 + fhalf;
+      f16x8 af[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int row = hbase[j] + hoff;
+        af[j] = *(const f16x8*)(Hs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int row = wn0 + i * 32 + frow;
+        wf[i] = *(const f16x8*)(Ws + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+    wcur = (wcur == 2) ? 0 : wcur + 1;
+    wnxt = (wnxt == 2) ? 0 : wnxt + 1;
+    if (++tap == 9) { tap = 0; ++cbl; }
+  }
+
+  // ---- epilogue.  Tile row r <-> pixel (y0 + r / TW, x0 + r % TW) of image `img`.
+  auto row_m = [&](int r, bool& ok) -> size_t {
+    const int y = y0 + r / TW, x = x0 + r % TW;
+    ok = (y < H) && (x < W);
+    return ((size_t)img * H + y) * W + x;
+  };
+  if (p.splits > 1) {
+    float* part = p.part + (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        bool ok;
+        const size_t m = row_m(wm0 + j * 32 + frow, ok);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn0 + i * 32 + 8 * q + 4 * fhalf;
+          if (ok && n + 4 <= p.N) {
+            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *(f32x4*)(part + m * p.N + n) = v;
+          }
+        }
+      }
+    return;
+  }
+  __syncthreads();
+  f16* stg = (f16*)smem;
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int ml = wm0 + j * 32 + frow;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nl = wn0 + i * 32 + 8 * q + 4 * fhalf;
+        f16x4 v = {(f16)acc[i][j][4 * q], (f16)acc[i][j][4 * q + 1], (f16)acc[i][j][4 * q + 2], (f16)acc[i][j][4 * q + 3]};
+        *(f16x4*)(stg + ml * SLD + nl) = v;
+      }
+    }
+  __syncthreads();
+  const int fl = p.flags;
+  constexpr int NC = BN / 8;
+  for (int idx = tid; idx < BM * NC; idx += 256) {
+    const int ml = idx / NC, nc = idx - ml * NC;
+    const int n = n0 + nc * 8;
+    bool ok;
+    const size_t m = row_m(ml, ok);
+    if (!ok || n + 8 > p.N) continue;  // N % 8 == 0 is required by the launcher
+    const f16x8 v = *(const f16x8*)(stg + ml * SLD + nc * 8);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
+    if (fl & GF_BIAS) {
+      const f32x4 t0 = *(const f32x4*)(p.bias + n), t1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[e] += t0[e]; x[4 + e] += t1[e]; }
+    }
+    if (fl & GF_RESID) {
+      const f16x8 r = *(const f16x8*)(p.R + m * p.ldr + n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += (float)r[e];
+    }
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)x[e];
+    *(f16x8*)((f16*)p.C + m * p.ldc + n) = o;
+  }
+}
+
+template <int TH, int TW, int BN>
+constexpr int halo_lds() {
+  constexpr int HP = (TH + 2) * (TW + 2), HL = (HP + 31) / 32;
+  return 2 * HL * 32 * 128 + 3 * BN * 128;
+}
+
+template <int TH, int TW, int BN>
+int launch_halo(const GemmParams& p, hipStream_t s) {
+  const int H = p.Hi, W = p.Wi;
+  const int blocks = (p.M / (H * W)) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * ((p.N + BN - 1) / BN);
+  constexpr int lds = halo_lds<TH, TW, BN>();
+  hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN>), dim3(blocks, 1, p.splits), dim3(256), lds, s, p);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
+
+}  // namespace
+
+template <int TH, int TW, int BN>
+static void set_halo_attr() {
+  constexpr int lds = halo_lds<TH, TW, BN>();
+  (void)hipFuncSetAttribute((const void*)conv_halo_kernel<TH, TW, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
+void dtp_conv_halo_init() {
+  set_halo_attr<8, 16, 64>();
+  set_halo_attr<8, 16, 128>();
+  set_halo_attr<8, 8, 64>();
+  set_halo_attr<8, 8, 128>();
+}
+
+// variant: 0 = 8x16 x 64, 1 = 8x16 x 128, 2 = 8x8 x 64, 3 = 8x8 x 128.  p.W must be the channel-block-major packing,
+// p.kb_per_split / p.splits count 64-channel blocks.
+bool dtp_conv_halo_supported(const GemmParams& p) {
+  return (p.flags & GF_CONV3) && !(p.flags & (GF_UPS2 | GF_GEGLU | GF_OUT_F32 | GF_LNFOLD | GF_ROWSTATS | GF_BIAS_M | GF_GELU | GF_QUICKGELU | GF_SILU)) &&
+         p.stride == 1 && p.pad == 1 && !p.A2 && (p.Cin & 63) == 0 && (p.N & 7) == 0 && p.Ho == p.Hi && p.Wo == p.Wi &&
+         (p.ldc & 7) == 0 && (!(p.flags & GF_RESID) || (p.ldr & 7) == 0) && p.M % (p.Hi * p.Wi) == 0;
+}
+
+int dtp_launch_conv_halo(const GemmParams& p, int variant, hipStream_t s) {
+  if (!dtp_conv_halo_supported(p)) { dtp_set_error("conv_halo: unsupported problem"); return DTP_ERR_ARG; }
+  int rc;
+  switch (variant) {
+    case 0: rc = launch_halo<8, 16, 64>(p, s); break;
+    case 1: rc = launch_halo<8, 16, 128>(p, s); break;
+    case 2: rc = launch_halo<8, 8, 64>(p, s); break;
+    case 3: rc = launch_halo<8, 8, 128>(p, s); break;
+    default: dtp_set_error("conv_halo: bad variant %d", variant); return DTP_ERR_ARG;
+  }
+  if (rc != DTP_OK) { dtp_set_error("conv_halo launch failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
+  if (p.splits > 1) return dtp_launch_splitk_reduce(p, s);
+  return DTP_OK;
+}

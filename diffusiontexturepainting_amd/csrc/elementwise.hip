@@ -55,6 +55,17 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
   }
 }
 
+// w [Cout][Cin][9] f32 -> out [Cout][ldw] f16 with k' = ((ci/64)*9 + tap)*64 + ci%64 (channel-block-major, Cin % 64 == 0)
+__global__ __launch_bounds__(256) void pack_conv_cb_kernel(const float* __restrict__ w, f16* __restrict__ out, int Cout, int Cin, int ldw) {
+  const long long total = (long long)Cout * Cin * 9;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int t = (int)(i % 9);
+    const long long oc = i / 9;
+    const int ci = (int)(oc % Cin), co = (int)(oc / Cin);
+    out[(size_t)co * ldw + ((ci >> 6) * 9 + t) * 64 + (ci & 63)] = (f16)w[i];
+  }
+}
+
 // w [N][K] f32 -> out[row_map ? row_map[n] : n][ldw] f16
 __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restrict__ w, f16* __restrict__ out, int N, int K,
                                                            int ldw, const int* __restrict__ row_map) {
@@ -173,5 +184,10 @@ int dtp_launch_scale_cols(float* w, const float* g, int N, int K, hipStream_t s)
 }
 int dtp_launch_rowsum_f16(const f16* w, int ld, int K, float* out, int rows, hipStream_t s) {
   hipLaunchKernelGGL(rowsum_f16_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, w, ld, K, out, rows);
+  LAUNCH_RET();
+}
+
+int dtp_launch_pack_conv_weight_cb(const float* w, f16* out, int Cout, int Cin, int ldw, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_cb_kernel, dim3(grid_for((long long)Cout * Cin * 9)), dim3(256), 0, s, w, out, Cout, Cin, ldw);
   LAUNCH_RET();
 }

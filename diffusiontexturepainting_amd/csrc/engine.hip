@@ -113,6 +113,12 @@ int load_conv(Ctx* c, const std::string& name, ConvW& w, int cin_pad, bool bias)
   RC(ctx_arena_alloc(c, up_to(cout, 128) * (size_t)w.ldw * 2, &p));
   w.w = (f16*)p;
   RC(dtp_launch_pack_conv_weight(s->d, w.w, cout, cin, cin_pad, taps, w.ldw, 0));
+  if (taps == 9 && (cin & 63) == 0) {  // second packing for the halo-tiled kernel
+    void* p2;
+    RC(ctx_arena_alloc(c, up_to(cout, 128) * (size_t)w.ldw * 2, &p2));
+    w.wcb = (f16*)p2;
+    RC(dtp_launch_pack_conv_weight_cb(s->d, w.wcb, cout, cin, w.ldw, 0));
+  }
   w.b = nullptr;
   if (bias) {
     const Staged* b = ctx_find(c, name + ".bias");
@@ -314,7 +320,7 @@ void tune_cache_load(Ctx* c) {
   char key[256];
   int tile, splits;
   while (fscanf(f, "%255s %d %d", key, &tile, &splits) == 3)
-    if (tile >= 0 && tile < 12 && splits >= 1 && splits <= 64) c->tuned[key] = std::make_pair(tile, splits);
+    if (tile >= 0 && tile < 16 && splits >= 1 && splits <= 64) c->tuned[key] = std::make_pair(tile, splits);
   fclose(f);
   c->tune_saved = c->tuned.size();
 }
@@ -381,11 +387,47 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
         if (ms < best) { best = ms; bt = tile; bs = sp; }
       }
     }
+    // halo-tiled 3x3 variants (tile ids 12..15); their split-K runs over 64-channel blocks
+    if (p.Wcb && dtp_conv_halo_supported(p)) {
+      const int ncb = p.Cin / 64;
+      static const int halo_splits[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20};
+      for (int v = 0; v < 4; ++v) {
+        if ((v >= 2) != (p.Hi * p.Wi <= 256)) continue;  // 8x8 pixel tiles for small feature maps, 8x16 otherwise
+        for (int sp : halo_splits) {
+          if (sp > ncb) break;
+          GemmParams q = p;
+          q.W = p.Wcb;
+          q.kb_per_split = (ncb + sp - 1) / sp;
+          q.splits = (ncb + q.kb_per_split - 1) / q.kb_per_split;
+          if (q.splits != sp) continue;
+          const size_t need = dtp_gemm_workspace_bytes(q);
+          if (need > ((size_t)512 << 20)) continue;
+          if (need > c->ws_bytes) { c->ws_need = std::max(c->ws_need, need); RC(ensure_ws(c)); }
+          q.part = c->ws;
+          q.zero = c->zero;
+          float ms = 1e30f;
+          for (int rep = 0; rep < 5; ++rep) {
+            HIP_CHECK(hipMemsetAsync(c->tune_thrash, rep, THRASH_BYTES, 0));
+            RC(dtp_launch_touch(q.A, a_bytes, (float*)c->tune_thrash, 0));
+            if (q.R) RC(dtp_launch_touch(q.R, (size_t)q.M * q.ldr * 2, (float*)c->tune_thrash, 0));
+            HIP_CHECK(hipEventRecord(c->tune_ev[0], 0));
+            RC(dtp_launch_conv_halo(q, v, 0));
+            HIP_CHECK(hipEventRecord(c->tune_ev[1], 0));
+            HIP_CHECK(hipEventSynchronize(c->tune_ev[1]));
+            float t = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&t, c->tune_ev[0], c->tune_ev[1]));
+            ms = std::min(ms, t);
+          }
+          if (ms < best) { best = ms; bt = 12 + v; bs = sp; }
+        }
+      }
+    }
     it = c->tuned.emplace(key, std::make_pair(bt, bs)).first;
   }
   *tile_out = it->second.first;
-  p.kb_per_split = (p.nkb + it->second.second - 1) / it->second.second;
-  p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
+  const int units = (*tile_out >= 12) ? p.Cin / 64 : p.nkb;  // halo variants split over channel blocks
+  p.kb_per_split = (units + it->second.second - 1) / it->second.second;
+  p.splits = (units + p.kb_per_split - 1) / p.kb_per_split;
   return DTP_OK;
 }
 
@@ -408,10 +450,11 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   char lab[160];
   snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
            p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? " geglu" : "", p.stride == 2 ? " s2" : "");
-  prog_push(c, prog, PK_GEMM0 + tile, 2.0 * p.M * (double)p.N * k_alg, bytes, [=](hipStream_t s, int step) {
+  prog_push(c, prog, tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile, 2.0 * p.M * (double)p.N * k_alg, bytes, [=](hipStream_t s, int step) {
     GemmParams q = p;
     q.part = c->ws;
     if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;
+    if (tile >= 12) { q.W = q.Wcb; return dtp_launch_conv_halo(q, tile - 12, s); }
     return dtp_launch_gemm(q, tile, s);
   }, lab);
   return DTP_OK;
@@ -429,6 +472,7 @@ int Builder::conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, in
   p.Hi = x.H; p.Wi = x.W; p.Ho = Ho; p.Wo = Wo; p.Cin = w.cin; p.stride = stride; p.pad = pad;
   p.flags = GF_CONV3 | (ups ? GF_UPS2 : 0) | extra_flags;
   if (tail) { p.A2 = tail->p; p.lda2 = tail->ld; p.Cin2 = w.cin2; }
+  p.Wcb = w.wcb;
   if (out_override) {
     y = T();
     y.p = (f16*)out_override; y.B = x.B; y.H = Ho; y.W = Wo; y.C = w.cout; y.ld = ldc_override;

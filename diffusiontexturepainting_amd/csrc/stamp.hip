@@ -15,6 +15,7 @@ int launch_vae_sample(Ctx* c, const float* mom, const float* eps, float* out, in
 int launch_post_quant(Ctx* c, const float* z, int nhwc, float in_scale, f16* out, int B, hipStream_t s);
 int load_imgenc_weights(Ctx* c);
 void dtp_gemm_init();
+void dtp_conv_halo_init();
 
 #define VAE_SCALE 0.18215f
 
@@ -270,6 +271,7 @@ int dtp_finalize_weights(dtp_ctx* ctx) {
   if (c->finalized) { dtp_set_error("dtp_finalize_weights: already finalized"); return DTP_ERR_STATE; }
   HIP_CHECK(hipSetDevice(c->device));
   dtp_gemm_init();
+  dtp_conv_halo_init();
   RC(load_unet_weights(c));
   RC(load_vae_weights(c));
   bool has_clip = false;

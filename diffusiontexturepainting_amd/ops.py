@@ -41,6 +41,16 @@ def pack_conv(w, cin_pad=None):
     return out
 
 
+def pack_conv_cb(w):
+    """w f32 [Cout,Cin,3,3] (Cin % 64 == 0) -> channel-block-major packing for the halo-tiled conv kernel."""
+    lib = _lib.load()
+    cout, cin = w.shape[:2]
+    out = torch.zeros(_up(cout, 128), 9 * cin, dtype=torch.float16, device=w.device)
+    w = w.contiguous().float()
+    check(lib.dtp_op_pack_conv_cb(ptr(w), ptr(out), cout, cin, out.shape[1], _stream()), "pack_conv_cb")
+    return out
+
+
 def rowsum(wp, k):
     """fp32 row sums of packed fp16 weights over the first k columns (the `lns` vector of a LayerNorm-folded GEMM)."""
     lib = _lib.load()
@@ -74,7 +84,7 @@ def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, ou
 
 
 def conv3x3(x, wp, cout, stride=1, pad=1, upsample=False, bias=None, resid=None, tile=-1, splits=0, out_hw=None, flags=0,
-            tail=None):
+            tail=None, wcb=None):
     """x f16 NHWC [B,H,W,C] -> f16 NHWC [B,Ho,Wo,cout].  pad is the top/left zero padding; bottom/right
     padding is implied by out_hw (default: the symmetric-padding output size)."""
     lib = _lib.load()
@@ -94,6 +104,8 @@ def conv3x3(x, wp, cout, stride=1, pad=1, upsample=False, bias=None, resid=None,
     d.conv, d.Hi, d.Wi, d.Ho, d.Wo, d.Cin, d.stride, d.pad, d.upsample2x = 1, h, w, ho, wo, cin, stride, pad, int(upsample)
     d.flags = flags | (GF_BIAS if bias is not None else 0) | (GF_RESID if resid is not None else 0)
     d.tile, d.splits = tile, splits
+    if wcb is not None:
+        d.Wcb = wcb.data_ptr()
     check(lib.dtp_op_gemm(C.byref(d), _stream()), "conv3x3")
     return out
 

@@ -131,12 +131,14 @@ typedef struct {
   int lda, ldw, ldc, ldr;
   int conv, Hi, Wi, Ho, Wo, Cin, stride, pad, upsample2x;
   int flags;         /* DTP_GF_* */
-  int tile;          /* -1 = heuristic; 0:128x128 1:128x64 2:64x64 3:64x128 (MxN) */
+  int tile;          /* -1 = heuristic; gemm_kernel: shape + 4*(stages-2), shape 0:128x128 1:128x64 2:64x64 3:64x128 (MxN),
+                        stages 2..4; 12..15 = conv_halo_kernel (8x16|8x8 pixel tile) x (64|128 channels), needs Wcb */
   int splits;        /* 0 = heuristic; >=1 = forced split-K factor */
   const float* lns;  /* DTP_GF_LNFOLD: row sums of the packed weights (dtp_op_rowsum) */
   float ln_eps;
   const void* A2;    /* conv only: fused 1x1-shortcut tail, f16 [M][lda2] with Cin2 channels appended to K (W = [W3x3 | W1x1]) */
   int lda2, Cin2;
+  const void* Wcb;   /* 3x3 conv: channel-block-major packing (dtp_op_pack_conv_cb); selects conv_halo_kernel when tile = 12..15 */
 } dtp_gemm_desc;
 enum { DTP_GF_BIAS = 1, DTP_GF_BIAS_M = 2, DTP_GF_RESID = 4, DTP_GF_GEGLU = 8, DTP_GF_GELU = 64, DTP_GF_QUICKGELU = 128,
        DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512, DTP_GF_LNFOLD = 1024 };
@@ -148,6 +150,8 @@ int dtp_op_pack_linear(const float* w, void* out, int N, int K, int ldw, int geg
 /* out[r] = sum_k w[r][k] over packed fp16 rows (the `lns` vector of a LayerNorm-folded GEMM) */
 int dtp_op_rowsum(const void* w, int ld, int K, float* out, int rows, dtp_stream s);
 int dtp_op_pack_conv(const float* w, void* out, int Cout, int Cin, int Cin_pad, int taps, int ldw, dtp_stream s);
+/* w f32 [Cout][Cin][3][3] -> out f16 [rows][ldw], k' = ((ci/64)*9 + tap)*64 + ci%64 (Cin % 64 == 0; caller zero-fills out) */
+int dtp_op_pack_conv_cb(const float* w, void* out, int Cout, int Cin, int ldw, dtp_stream s);
 int dtp_op_groupnorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
                      int groups, float eps, int silu, dtp_stream s);
 int dtp_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int rows, int C,

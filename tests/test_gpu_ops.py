@@ -183,6 +183,29 @@ def test_conv3x3_fused_shortcut(ops, b, h, cin, cin2, cout, tile, splits):
     close(got, ref.permute(0, 2, 3, 1))
 
 
+HALO_CASES = [
+    # B, H, W, Cin, Cout, variant(12..15), splits
+    (3, 64, 64, 320, 320, 12, 1), (3, 64, 64, 320, 320, 13, 1), (2, 32, 32, 640, 640, 13, 2), (3, 16, 16, 1280, 1280, 14, 4),
+    (3, 8, 8, 1280, 1280, 15, 5), (1, 24, 40, 128, 128, 12, 1), (2, 12, 20, 64, 64, 14, 1), (1, 128, 128, 128, 256, 13, 1),
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv3x3_halo_kernel(ops, case):
+    """The halo-tiled kernel (input patch staged once per 64-channel block, reused by all 9 taps) vs torch conv2d."""
+    b, h, w, cin, cout, variant, splits = case
+    x = rnd(b, h, w, cin, seed=33)
+    wt = rnd(cout, cin, 3, 3, seed=34, scale=(9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(35))
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float(), bias, padding=1).permute(0, 2, 3, 1)
+    res = rnd(*ref.shape, seed=36)
+    ref = ref + res.float()
+    wf = wt.float().cuda()
+    got = ops.conv3x3(x.cuda(), ops.pack_conv(wf), cout, bias=bias.cuda(), resid=res.cuda(), wcb=ops.pack_conv_cb(wf), tile=variant,
+                      splits=splits)
+    close(got, ref)
+
+
 def test_conv3x3_strided_view_and_f32_out(ops):
     """Input is a channel slice of a wider NHWC buffer (lda > Cin); output fp32."""
     from diffusiontexturepainting_amd._lib import GF_OUT_F32

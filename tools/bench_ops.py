@@ -87,3 +87,26 @@ if __name__ == "__main__":
         if what in ("conv", "all"): conv_suite()
         if what in ("attn", "all"): attn_suite()
         if what in ("norm", "all"): norm_suite()
+
+
+def halo_suite():
+    shapes = [(3, 64, 320, 320), (3, 64, 640, 320), (3, 32, 640, 640), (3, 32, 1280, 640), (3, 16, 1280, 1280), (3, 8, 1280, 1280),
+              (1, 512, 128, 128), (1, 256, 256, 256), (1, 128, 512, 512), (24, 64, 320, 320), (24, 16, 1280, 1280)]
+    for b, hw, cin, cout in shapes:
+        x = torch.randn(b, hw, hw, cin, device="cuda", dtype=torch.float16)
+        w = torch.randn(cout, cin, 3, 3, device="cuda") * (9 * cin) ** -0.5
+        wp, wcb = ops.pack_conv(w), ops.pack_conv_cb(w)
+        fl = 2.0 * b * hw * hw * cout * 9 * cin
+        row = []
+        for tile in (0, 1, 5, 12, 13, 14, 15):
+            for sp in (1, 4):
+                if sp > 1 and b * hw * hw > 1024:
+                    continue
+                t = timeit(lambda: ops.conv3x3(x, wp, cout, tile=tile, splits=sp, wcb=wcb), iters=10)
+                row.append(f"t{tile}/s{sp}:{fl/t/1e12:6.0f}")
+        print(f"halo B={b:2d} HW={hw:3d} Cin={cin:4d} Cout={cout:4d} | " + " ".join(row), flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "halo":
+    with torch.cuda.stream(torch.cuda.Stream()):
+        halo_suite()
