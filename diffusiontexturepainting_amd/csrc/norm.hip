@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
   const long long total = (long long)HW * nch;
   const f16* xb = x + (size_t)b * HW * ldx;
   f16* yb = y + (size_t)b * HW * ldy;
+#pragma unroll 2
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long pix = i / nch;
     const int c0 = (int)(i - pix * nch) * 8;
@@ -132,11 +133,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
 // is a whole number of 16-byte chunks.  Pass 1 accumulates per-group sums in registers (fixed-order
 // wave + LDS reduction, deterministic), pass 2 re-reads the slab (L2 resident) and normalises.
 template <int G>
-__global__ __launch_bounds__(256) void gn_fused_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy,
+__global__ __launch_bounds__(1024) void gn_fused_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int HW,
                                                         int cpg, int silu, float inv_count, float eps) {
-  __shared__ float red[4][2 * G];
+  __shared__ float red[16][2 * G];
   __shared__ float st[2 * G];
+  const int nthr = blockDim.x, nwave = blockDim.x >> 6;
   const int b = blockIdx.y, slab = blockIdx.x;
   const int cs = slab * G * cpg;          // first channel of the slab
   const int nchs = (G * cpg) >> 3;        // 16-byte chunks per pixel inside the slab
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const f16* __restrict__ x
 #pragma unroll
   for (int g = 0; g < G; ++g) s[g] = q[g] = 0.f;
   const int total = HW * nchs;
-  for (int i = threadIdx.x; i < total; i += 256) {
+  for (int i = threadIdx.x; i < total; i += nthr) {
     const int pix = i / nchs, c0 = (i - pix * nchs) * 8;
     const f16x8 v = *(const f16x8*)(xb + (size_t)pix * ldx + c0);
     const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
@@ -174,14 +176,14 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const f16* __restrict__ x
   __syncthreads();
   if (threadIdx.x < G) {
     const int g = threadIdx.x;
-    const float ss = red[0][2 * g] + red[1][2 * g] + red[2][2 * g] + red[3][2 * g];
-    const float qq = red[0][2 * g + 1] + red[1][2 * g + 1] + red[2][2 * g + 1] + red[3][2 * g + 1];
+    float ss = 0.f, qq = 0.f;
+    for (int w = 0; w < nwave; ++w) { ss += red[w][2 * g]; qq += red[w][2 * g + 1]; }
     const float mean = ss * inv_count;
     st[2 * g] = mean;
     st[2 * g + 1] = rsqrtf(fmaxf(qq * inv_count - mean * mean, 0.f) + eps);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < total; i += 256) {
+  for (int i = threadIdx.x; i < total; i += nthr) {
     const int pix = i / nchs, c0 = (i - pix * nchs) * 8;
     const f16x8 v = *(const f16x8*)(xb + (size_t)pix * ldx + c0);
     const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
@@ -270,9 +272,9 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* __restrict
 }  // namespace
 
 static int gn_chunks(int HW) {  // pixel chunks per batch item for the statistics pass (more chunks = more loads in flight)
-  int n = HW / 16;
+  int n = HW / 64;
   if (n < 1) n = 1;
-  if (n > 256) n = 256;
+  if (n > 128) n = 128;
   return n;
 }
 
@@ -294,19 +296,24 @@ int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* ga
     if (G <= 4 && groups % G == 0) {
       const float inv = 1.0f / ((float)HW * cpg);
       dim3 grid(groups / G, B);
-      if (G == 1) hipLaunchKernelGGL((gn_fused_kernel<1>), grid, dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, HW, cpg, silu, inv, eps);
-      else if (G == 2) hipLaunchKernelGGL((gn_fused_kernel<2>), grid, dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, HW, cpg, silu, inv, eps);
-      else hipLaunchKernelGGL((gn_fused_kernel<4>), grid, dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, HW, cpg, silu, inv, eps);
+      const int items = HW * ((G * cpg) >> 3);  // 16-byte chunks per block: one or two per thread
+      const dim3 blk(items >= 2048 ? 1024 : (items >= 512 ? 512 : 256));
+      if (G == 1) hipLaunchKernelGGL((gn_fused_kernel<1>), grid, blk, 0, s, x, ldx, y, ldy, gamma, beta, HW, cpg, silu, inv, eps);
+      else if (G == 2) hipLaunchKernelGGL((gn_fused_kernel<2>), grid, blk, 0, s, x, ldx, y, ldy, gamma, beta, HW, cpg, silu, inv, eps);
+      else hipLaunchKernelGGL((gn_fused_kernel<4>), grid, blk, 0, s, x, ldx, y, ldy, gamma, beta, HW, cpg, silu, inv, eps);
       return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
     }
   }
   const int nch = C / 8;
-  int rows = 256 / nch;
+  const int nchunk = gn_chunks(HW);
+  const int ppc = (HW + nchunk - 1) / nchunk;
+  // few, fat blocks: up to 1024 threads so that many 16-byte loads are in flight per block while the number of
+  // partial sums the apply kernel has to re-reduce stays small
+  int rows = 1024 / nch;
+  if (rows > ppc) rows = ppc;
   if (rows < 1) rows = 1;
   const int threads = nch * rows;
   if (threads > 1024) { dtp_set_error("groupnorm: C too large"); return DTP_ERR_ARG; }
-  const int nchunk = gn_chunks(HW);
-  const int ppc = (HW + nchunk - 1) / nchunk;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(threads), 0, s, x, ldx, ws, HW, C, cpg, groups, ppc);
   const long long per_batch = (long long)HW * nch;
   long long bx = (per_batch + 255) / 256;
