@@ -86,9 +86,9 @@ int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s) {
   if (tile >= 12) {  // halo-tiled 3x3 conv: split-K counts 64-channel blocks
     if (!d->Wcb) { dtp_set_error("conv_halo: Wcb missing"); return DTP_ERR_ARG; }
     p.W = (const f16*)d->Wcb;
-    const int ncb = p.Cin / 64, sp = d->splits >= 1 ? d->splits : 1;
-    p.kb_per_split = (ncb + sp - 1) / sp;
-    p.splits = (ncb + p.kb_per_split - 1) / p.kb_per_split;
+    const int sp = d->splits >= 1 ? d->splits : 1;
+    p.kb_per_split = (p.nkb + sp - 1) / sp;
+    p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
   }
   rc = ops_ws(dtp_gemm_workspace_bytes(p));
   if (rc) return rc;

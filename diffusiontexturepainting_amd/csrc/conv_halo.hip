@@ -52,23 +52,28 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
   const int ty = rest % tiles_y;
   const int img = rest / tiles_y;
   const int y0 = ty * TH, x0 = tx * TW, n0 = tile_n * BN;
-  const int ncb = p.Cin >> 6;                       // 64-channel blocks
-  const int cb0 = blockIdx.z * p.kb_per_split;      // split-K over channel blocks (kb_per_split counts channel blocks here)
-  const int ncbl = min(p.kb_per_split, ncb - cb0);
-  const int nit = ncbl * 9;
+  // k-block sequence: nmain = 9 per 64-channel block (channel-block-major), then Cin2/64 dense "shortcut" blocks that
+  // read the ResBlock input A2 at the output pixel itself (the fused 1x1 conv).  Split-K cuts this sequence anywhere.
+  const int ncb = p.Cin >> 6, nmain = ncb * 9, ntail = p.A2 ? (p.Cin2 >> 6) : 0, ntot = nmain + ntail;
+  const int ita = blockIdx.z * p.kb_per_split;
+  const int nit = min(p.kb_per_split, ntot - ita);
+  const int itb = ita + nit;
 
-  // ---- halo DMA source: instruction i of this wave covers halo rows (i*4 + wave)*8 .. +7; lane -> (row, slot)
+  // ---- A-side DMA sources.  Instruction i of this wave covers LDS rows (i*4 + wave)*8 .. +7; lane -> (row, slot).
+  // halo blocks: row = halo pixel; shortcut blocks: row = tile row.
   const int kc8 = lane & 7;
-  const f16* hsrc[HL];
-  int hkc[HL];
+  const f16 *hsrc[HL], *tsrc[HL];
 #pragma unroll
   for (int i = 0; i < HL; ++i) {
     const int hp = (i * 4 + wave) * 8 + (lane >> 3);
+    const int kc = ((kc8 ^ ((hp >> 1) & 7)) << 3);
     const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
     const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
     const bool ok = (hp < HP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
-    hkc[i] = ((kc8 ^ ((hp >> 1) & 7)) << 3);
-    hsrc[i] = ok ? p.A + ((size_t)(img * H + iy) * W + ix) * p.lda + hkc[i] : nullptr;
+    hsrc[i] = ok ? p.A + ((size_t)(img * H + iy) * W + ix) * p.lda + kc : nullptr;
+    const int ty2 = y0 + hp / TW, tx2 = x0 + hp % TW;  // hp reinterpreted as a tile row
+    const bool ok2 = p.A2 && (hp < BM) && (ty2 < H) && (tx2 < W);
+    tsrc[i] = ok2 ? p.A2 + ((size_t)(img * H + ty2) * W + tx2) * p.lda2 + kc : nullptr;
   }
   const int lrow = wave * 8 + (lane >> 3);
   const int wkc = ((kc8 ^ ((lrow >> 1) & 7)) << 3);
@@ -76,12 +81,17 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
 #pragma unroll
   for (int i = 0; i < WR; ++i) w_row[i] = p.W + (size_t)(n0 + i * 32 + lrow) * p.ldw + wkc;
 
-  auto issue_halo = [&](int buf, int cb) {
+  auto issue_a = [&](int buf, int blk) {  // blk < ncb: halo of channel block blk; else shortcut block blk - ncb
     char* dst = halo + buf * HBYTES;
+    if (blk < ncb) {
 #pragma unroll
-    for (int i = 0; i < HL; ++i) glds16(hsrc[i] ? hsrc[i] + (size_t)cb * 64 : p.zero, dst + (i * 4 + wave) * 8 * 128);
+      for (int i = 0; i < HL; ++i) glds16(hsrc[i] ? hsrc[i] + (size_t)blk * 64 : p.zero, dst + (i * 4 + wave) * 8 * 128);
+    } else {
+#pragma unroll
+      for (int i = 0; i < HL; ++i) glds16(tsrc[i] ? tsrc[i] + (size_t)(blk - ncb) * 64 : p.zero, dst + (i * 4 + wave) * 8 * 128);
+    }
   };
-  auto issue_w = [&](int buf, int it) {  // it = absolute k-block index (cb*9 + tap)
+  auto issue_w = [&](int buf, int it) {  // it = absolute k-block index
     char* dst = wring + buf * WBYTES;
 #pragma unroll
     for (int i = 0; i < WR; ++i) glds16(w_row[i] + (size_t)it * 64, dst + (i * 32 + wave * 8) * 128);
@@ -104,24 +114,31 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
     hbase[j] = (r / TW) * (TW + 2) + (r % TW);
   }
 
-  // ---- prologue: halo(cb0), W(0), W(1)
-  const int it0 = cb0 * 9;
+  // ---- pipeline state for absolute k-block `it`: block id blk (channel block, or ncb + shortcut block), tap inside it
+  int blk = (ita < nmain) ? ita / 9 : ncb + (ita - nmain);
+  int tap = (ita < nmain) ? ita - blk * 9 : 0;
   if (nit > 0) {
-    issue_halo(0, cb0);
-    issue_w(0, it0);
-    if (nit > 1) issue_w(1, it0 + 1);
+    issue_a(0, blk);
+    issue_w(0, ita);
+    if (nit > 1) issue_w(1, ita + 1);
   }
-  int wcur = 0, wnxt = 2, tap = 0, cbl = 0;  // ring slot of W(t) / of W(t+2); tap and local channel block of iteration t
+  int wcur = 0, wnxt = 2, abuf = 0;
+  bool changed = false, refilled_prev = false;
   for (int t = 0; t < nit; ++t) {
-    // W(t) (and the halo it needs) have landed once only the younger groups of this wave are outstanding:
-    // W(t+1) [+ the halo refill issued at tap 0 of this channel block, which is younger than W(t) only when t-1 had tap 0]
+    const int it = ita + t;
+    // W(t) and the A block of this iteration have landed once only younger DMA groups of this wave are outstanding:
+    // W(t+1), plus the A refill issued at t-1 unless that refill is the very block needed now.
     if (t + 1 >= nit) wait_vmcnt<0>();
-    else if (tap == 1 && cbl + 1 < ncbl) wait_vmcnt<WR + HL>();
+    else if (refilled_prev && !changed) wait_vmcnt<WR + HL>();
     else wait_vmcnt<WR>();
     __builtin_amdgcn_s_barrier();
-    if (tap == 0 && cbl + 1 < ncbl) issue_halo((cbl + 1) & 1, cb0 + cbl + 1);
-    if (t + 2 < nit) issue_w(wnxt, it0 + t + 2);
-    const char* Hs = halo + (cbl & 1) * HBYTES;
+    // the first iteration of every block launches the DMA of the next block (if it is inside this split's range)
+    const bool tail = blk >= ncb;
+    const int next_start = tail ? it + 1 : (blk + 1) * 9;
+    const bool do_refill = (t == 0 || changed) && (next_start < itb);
+    if (do_refill) issue_a(abuf ^ 1, blk + 1);
+    if (t + 2 < nit) issue_w(wnxt, it + 2);
+    const char* Hs = halo + abuf * HBYTES;
     const char* Ws = wring + wcur * WBYTES;
     const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
     const int hoff = ky * (TW + 2) + kx;
@@ -131,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
       f16x8 af[TM], wf[TN];
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        const int row = hbase[j] + hoff;
+        const int row = tail ? (wm0 + j * 32 + frow) : (hbase[j] + hoff);
         af[j] = *(const f16x8*)(Hs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
@@ -146,7 +163,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
     }
     wcur = (wcur == 2) ? 0 : wcur + 1;
     wnxt = (wnxt == 2) ? 0 : wnxt + 1;
-    if (++tap == 9) { tap = 0; ++cbl; }
+    refilled_prev = do_refill;
+    // advance to k-block it+1
+    changed = false;
+    if (tail) { ++blk; changed = true; }
+    else if (++tap == 9) { tap = 0; ++blk; changed = true; }
+    if (changed) abuf ^= 1;
   }
 
   // ---- epilogue.  Tile row r <-> pixel (y0 + r / TW, x0 + r % TW) of image `img`.
@@ -248,11 +270,12 @@ void dtp_conv_halo_init() {
   set_halo_attr<8, 8, 128>();
 }
 
-// variant: 0 = 8x16 x 64, 1 = 8x16 x 128, 2 = 8x8 x 64, 3 = 8x8 x 128.  p.W must be the channel-block-major packing,
-// p.kb_per_split / p.splits count 64-channel blocks.
+// variant: 0 = 8x16 x 64, 1 = 8x16 x 128, 2 = 8x8 x 64, 3 = 8x8 x 128.  p.W must be the channel-block-major packing
+// ([cb][tap][64] then the fused-shortcut columns); p.kb_per_split / p.splits count 64-wide k-blocks like gemm_kernel.
 bool dtp_conv_halo_supported(const GemmParams& p) {
   return (p.flags & GF_CONV3) && !(p.flags & (GF_UPS2 | GF_GEGLU | GF_OUT_F32 | GF_LNFOLD | GF_ROWSTATS | GF_BIAS_M | GF_GELU | GF_QUICKGELU | GF_SILU)) &&
-         p.stride == 1 && p.pad == 1 && !p.A2 && (p.Cin & 63) == 0 && (p.N & 7) == 0 && p.Ho == p.Hi && p.Wo == p.Wi &&
+         p.stride == 1 && p.pad == 1 && (!p.A2 || ((p.Cin2 & 63) == 0 && (p.lda2 & 7) == 0)) && (p.Cin & 63) == 0 &&
+         (p.N & 7) == 0 && p.Ho == p.Hi && p.Wo == p.Wi &&
          (p.ldc & 7) == 0 && (!(p.flags & GF_RESID) || (p.ldr & 7) == 0) && p.M % (p.Hi * p.Wi) == 0;
 }
 

@@ -144,6 +144,11 @@ int load_conv_with_shortcut(Ctx* c, const std::string& conv, const std::string& 
   w.w = (f16*)p;
   RC(dtp_launch_pack_conv_weight(s->d, w.w, cout, cin, cin, 9, w.ldw, 0));
   RC(dtp_launch_pack_conv_weight(t->d, w.w + 9 * cin, cout, cin2, cin2, 1, w.ldw, 0));
+  void* p2;  // halo-kernel packing: channel-block-major 3x3 part, same shortcut columns
+  RC(ctx_arena_alloc(c, up_to(cout, 128) * (size_t)w.ldw * 2, &p2));
+  w.wcb = (f16*)p2;
+  RC(dtp_launch_pack_conv_weight_cb(s->d, w.wcb, cout, cin, w.ldw, 0));
+  RC(dtp_launch_pack_conv_weight(t->d, w.wcb + 9 * cin, cout, cin2, cin2, 1, w.ldw, 0));
   std::vector<float> b1, b2;
   RC(ctx_fetch_host(c, conv + ".bias", b1));
   RC(ctx_fetch_host(c, shortcut + ".bias", b2));
@@ -388,18 +393,17 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
       }
     }
     // halo-tiled 3x3 variants (tile ids 12..15); their split-K runs over 64-channel blocks
-    if (p.Wcb && dtp_conv_halo_supported(p)) {
-      const int ncb = p.Cin / 64;
-      static const int halo_splits[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20};
+    static const bool no_halo_tail = getenv("DTP_NO_HALO_TAIL") != nullptr;  // A/B switch for measurements
+    if (p.Wcb && dtp_conv_halo_supported(p) && !(no_halo_tail && p.A2)) {
       for (int v = 0; v < 4; ++v) {
         if ((v >= 2) != (p.Hi * p.Wi <= 256)) continue;  // 8x8 pixel tiles for small feature maps, 8x16 otherwise
-        for (int sp : halo_splits) {
-          if (sp > ncb) break;
+        for (int sp : cand_splits) {
+          if (sp > 1 && p.nkb / sp < 9) break;
           GemmParams q = p;
           q.W = p.Wcb;
-          q.kb_per_split = (ncb + sp - 1) / sp;
-          q.splits = (ncb + q.kb_per_split - 1) / q.kb_per_split;
-          if (q.splits != sp) continue;
+          q.kb_per_split = (p.nkb + sp - 1) / sp;
+          q.splits = (p.nkb + q.kb_per_split - 1) / q.kb_per_split;
+          if (q.splits != sp && sp > 1) continue;
           const size_t need = dtp_gemm_workspace_bytes(q);
           if (need > ((size_t)512 << 20)) continue;
           if (need > c->ws_bytes) { c->ws_need = std::max(c->ws_need, need); RC(ensure_ws(c)); }
@@ -425,9 +429,8 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     it = c->tuned.emplace(key, std::make_pair(bt, bs)).first;
   }
   *tile_out = it->second.first;
-  const int units = (*tile_out >= 12) ? p.Cin / 64 : p.nkb;  // halo variants split over channel blocks
-  p.kb_per_split = (units + it->second.second - 1) / it->second.second;
-  p.splits = (units + p.kb_per_split - 1) / p.kb_per_split;
+  p.kb_per_split = (p.nkb + it->second.second - 1) / it->second.second;
+  p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
   return DTP_OK;
 }
 

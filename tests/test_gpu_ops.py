@@ -206,6 +206,22 @@ def test_conv3x3_halo_kernel(ops, case):
     close(got, ref)
 
 
+@pytest.mark.parametrize("b,h,cin,cin2,cout,variant,splits", [(2, 16, 64, 128, 64, 12, 1), (3, 8, 320, 640, 320, 14, 1), (1, 16, 128, 64, 256, 13, 3),
+                                                              (3, 8, 1280, 2560, 1280, 15, 7), (2, 32, 320, 960, 320, 12, 2)])
+def test_conv3x3_halo_fused_shortcut(ops, b, h, cin, cin2, cout, variant, splits):
+    """Halo kernel with the ResBlock's 1x1 shortcut appended as dense k-blocks; split-K cuts the k-block sequence anywhere."""
+    t, x = rnd(b, h, h, cin, seed=44), rnd(b, h, h, cin2, seed=45)
+    w3 = rnd(cout, cin, 3, 3, seed=46, scale=(9 * cin) ** -0.5)
+    w1 = rnd(cout, cin2, 1, 1, seed=47, scale=cin2 ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(48))
+    ref = F.conv2d(t.float().permute(0, 3, 1, 2), w3.float(), bias, padding=1) + F.conv2d(x.float().permute(0, 3, 1, 2), w1.float())
+    w1p = ops.pack_conv(w1.float().cuda())[:, :cin2]
+    wp = torch.cat([ops.pack_conv(w3.float().cuda())[:, : 9 * cin], w1p], dim=1).contiguous()
+    wcb = torch.cat([ops.pack_conv_cb(w3.float().cuda()), w1p], dim=1).contiguous()
+    got = ops.conv3x3(t.cuda(), wp, cout, bias=bias.cuda(), tail=x.cuda(), wcb=wcb, tile=variant, splits=splits)
+    close(got, ref.permute(0, 2, 3, 1))
+
+
 def test_conv3x3_strided_view_and_f32_out(ops):
     """Input is a channel slice of a wider NHWC buffer (lda > Cin); output fp32."""
     from diffusiontexturepainting_amd._lib import GF_OUT_F32
