@@ -6,7 +6,7 @@ import os
 import torch  # noqa: F401  -- must come first: libdtp.so has to bind to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdtp.so")
+LIB_PATH = os.environ.get("DTP_LIB") or os.path.join(_HERE, "libdtp.so")  # DTP_LIB: A/B another build of the same ABI
 _lib = None
 
 
@@ -27,7 +27,8 @@ _SHAPES = [(128, 128), (128, 64), (64, 64), (64, 128)]
 PROF_KINDS = [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 4}>" for i in range(12)] + \
     ["attention_kernel", "groupnorm (gn_stats+gn_apply | gn_fused)", "layernorm_kernel", "concat_kernel / small elementwise",
      "softmax_rows_kernel", "conv_halo_kernel<8, 16, 64>", "conv_halo_kernel<8, 16, 128>", "conv_halo_kernel<8, 8, 64>",
-     "conv_halo_kernel<8, 8, 128>"]
+     "conv_halo_kernel<8, 8, 128>", "gemm_kernel<256, 128, 2>", "gemm_kernel<256, 128, 3>", "gemm_kernel<128, 256, 2>",
+     "gemm_kernel<128, 256, 3>"]
 
 
 class GemmDesc(C.Structure):

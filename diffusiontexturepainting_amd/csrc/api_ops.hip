@@ -83,7 +83,7 @@ int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s) {
     p.kb_per_split = (p.nkb + d->splits - 1) / d->splits;
     p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
   }
-  if (tile >= 12) {  // halo-tiled 3x3 conv: split-K counts 64-channel blocks
+  if (tile >= 12 && tile < 16) {  // halo-tiled 3x3 conv: split-K counts 64-channel blocks
     if (!d->Wcb) { dtp_set_error("conv_halo: Wcb missing"); return DTP_ERR_ARG; }
     p.W = (const f16*)d->Wcb;
     const int sp = d->splits >= 1 ? d->splits : 1;
@@ -93,7 +93,7 @@ int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s) {
   rc = ops_ws(dtp_gemm_workspace_bytes(p));
   if (rc) return rc;
   p.part = g_ops.ws;
-  if (tile >= 12) return dtp_launch_conv_halo(p, tile - 12, (hipStream_t)s);
+  if (tile >= 12 && tile < 16) return dtp_launch_conv_halo(p, tile - 12, (hipStream_t)s);
   return dtp_launch_gemm(p, tile, (hipStream_t)s);
 }
 

@@ -12,6 +12,36 @@ typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- hand-scheduled LDS fragment reads (GEMM-style kernels).  With global_load_lds in a loop the compiler treats every
+// LDS-DMA as a possible out-of-order LGKM event and only ever emits s_waitcnt lgkmcnt(0); these untracked reads plus
+// hand-counted waits let the MFMAs of k-step s run while the reads of steps s+1.. are still in flight.
+// LDS byte address of a pointer into the dynamic shared segment
+static __device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+// ds_read_b128 the compiler does not track: pair every use with wait_lds_frags<>
+static __device__ __forceinline__ f16x8 lds_read16(uint32_t addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+// s_waitcnt lgkmcnt(N) that the NF fragments "pass through", so their consumers cannot be scheduled above the wait
+template <int N, int NF>
+static __device__ __forceinline__ void wait_lds_frags(f16x8 (&f)[NF]) {
+  static_assert(NF == 2 || NF == 3 || NF == 4 || NF == 6 || NF == 8, "fragment count");
+  if constexpr (NF == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(N));
+  else if constexpr (NF == 3) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : "n"(N));
+  else if constexpr (NF == 4) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N));
+  else if constexpr (NF == 6)
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(N));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])
+                 : "n"(N));
+}
+
+
+
 #define DTP_WAVE 64
 
 #define HIP_CHECK(x)                                                                        \
@@ -73,6 +103,7 @@ struct GemmParams {
 // tile: shape + 4 * (stages - 2); shape 0 = 128x128, 1 = 128(M)x64(N), 2 = 64x64, 3 = 64(M)x128(N); stages 2..4
 int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s);
 int dtp_launch_splitk_reduce(const GemmParams& p, hipStream_t s);
+bool dtp_gemm_tile_dims(int tile, int* bm, int* bn, int* ns);
 size_t dtp_gemm_workspace_bytes(const GemmParams& p);
 void dtp_gemm_pick(GemmParams& p, int* tile, int num_cu);  // sets splits/kb_per_split
 

@@ -9,6 +9,8 @@
 // Same MFMA mapping, LDS swizzle, epilogue and split-K convention as gemm_kernel (see gemm_conv.hip); the
 // pipeline is: weights in a 3-deep ring (counted vmcnt, raw s_barrier per tap), halo double-buffered and
 // refilled during tap 0 of the previous channel block.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -124,52 +126,97 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
   }
   int wcur = 0, wnxt = 2, abuf = 0;
   bool changed = false, refilled_prev = false;
-  for (int t = 0; t < nit; ++t) {
-    const int it = ita + t;
-    // W(t) and the A block of this iteration have landed once only younger DMA groups of this wave are outstanding:
-    // W(t+1), plus the A refill issued at t-1 unless that refill is the very block needed now.
-    if (t + 1 >= nit) wait_vmcnt<0>();
-    else if (refilled_prev && !changed) wait_vmcnt<WR + HL>();
-    else wait_vmcnt<WR>();
-    __builtin_amdgcn_s_barrier();
-    // the first iteration of every block launches the DMA of the next block (if it is inside this split's range)
-    const bool tail = blk >= ncb;
-    const int next_start = tail ? it + 1 : (blk + 1) * 9;
-    const bool do_refill = (t == 0 || changed) && (next_start < itb);
-    if (do_refill) issue_a(abuf ^ 1, blk + 1);
-    if (t + 2 < nit) issue_w(wnxt, it + 2);
+  auto a_piece = [&](int buf, int b2, int i) {  // piece i of the halo / shortcut block b2
+    char* dst = halo + buf * HBYTES + (i * 4 + wave) * 8 * 128;
+    if (b2 < ncb) glds16(hsrc[i] ? hsrc[i] + (size_t)b2 * 64 : p.zero, dst);
+    else glds16(tsrc[i] ? tsrc[i] + (size_t)(b2 - ncb) * 64 : p.zero, dst);
+  };
+  auto w_piece = [&](int buf, int it2, int i) { glds16(w_row[i] + (size_t)it2 * 64, wring + buf * WBYTES + (i * 32 + wave * 8) * 128); };
+  auto kblock = [&](auto issue_w_c, bool refill, int it, bool tail) {
+    constexpr bool ISSUE_W = decltype(issue_w_c)::value;
+    constexpr int NM = TM * TN, NH = HL, NP = NH + (ISSUE_W ? WR : 0);
     const char* Hs = halo + abuf * HBYTES;
     const char* Ws = wring + wcur * WBYTES;
     const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
     const int hoff = ky * (TW + 2) + kx;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    // fragments of k-step ks live in fr[ks % LA]: [0,TM) activations, [TM,TM+TN) weights (see gemm_conv.hip / common.h)
+    constexpr int NF = TM + TN, LA = (4 * NF <= 16) ? 4 : 2;
+    f16x8 fr[LA][NF];
+    const uint32_t h_lds = lds_addr(Hs), w_lds = lds_addr(Ws);
+    auto read_step = [&](int ks) {
       const int c = ks * 2 + fhalf;
-      f16x8 af[TM], wf[TN];
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int row = tail ? (wm0 + j * 32 + frow) : (hbase[j] + hoff);
-        af[j] = *(const f16x8*)(Hs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        fr[ks % LA][j] = lds_read16(h_lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int row = wn0 + i * 32 + frow;
-        wf[i] = *(const f16x8*)(Ws + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        fr[ks % LA][TM + i] = lds_read16(w_lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
       }
+    };
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    for (int ks = 0; ks < LA; ++ks) read_step(ks);
+    // pieces in issue order: q < NH halo, then W; piece q goes into k-step q / ceil(NP/4), so the order is kept
+    constexpr int PPS = (NP + 3) / 4;  // pieces per k-step (<= 3)
+#define DTP_PIECE(q)                                                                                        \
+    if constexpr ((q) < NP) {                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      if constexpr ((q) < NH) { if (refill) a_piece(abuf ^ 1, blk + 1, (q)); }                              \
+      else w_piece(wnxt, it + 2, (q) - NH);                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
-    wcur = (wcur == 2) ? 0 : wcur + 1;
-    wnxt = (wnxt == 2) ? 0 : wnxt + 1;
-    refilled_prev = do_refill;
-    // advance to k-block it+1
-    changed = false;
-    if (tail) { ++blk; changed = true; }
-    else if (++tap == 9) { tap = 0; ++blk; changed = true; }
-    if (changed) abuf ^= 1;
-  }
+#define DTP_MMA_STEP(ks)                                                                                    \
+    {                                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      wait_lds_frags<((ks + LA < 4 ? ks + LA : 4) - ks - 1) * NF, NF>(fr[ks % LA]);                         \
+      _Pragma("unroll") for (int i = 0; i < TN; ++i) _Pragma("unroll") for (int j = 0; j < TM; ++j) {       \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[ks % LA][TM + i], fr[ks % LA][j], acc[i][j], 0, 0, 0); \
+        if constexpr (PPS >= 1) { if (i * TM + j == 0) { DTP_PIECE(ks * PPS) } }                            \
+        if constexpr (PPS >= 2) { if (i * TM + j == NM / PPS) { DTP_PIECE(ks * PPS + 1) } }                 \
+        if constexpr (PPS >= 3) { if (i * TM + j == 2 * NM / PPS) { DTP_PIECE(ks * PPS + 2) } }             \
+      }                                                                                                     \
+      if constexpr (ks + LA < 4) {                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        read_step(ks + LA);                                                                                 \
+      }                                                                                                     \
+    }
+    DTP_MMA_STEP(0) DTP_MMA_STEP(1) DTP_MMA_STEP(2) DTP_MMA_STEP(3)
+#undef DTP_MMA_STEP
+#undef DTP_PIECE
+  };
+  // Two loops (steady state, then the last two k-blocks that issue no W) rather than one loop holding both bodies: with
+  // both in one loop the compiler shuffles the accumulators between AGPRs and VGPRs on every iteration.
+  auto run = [&](auto issue_w_c, int t_begin, int t_end) {
+    for (int t = t_begin; t < t_end; ++t) {
+      const int it = ita + t;
+      // W(t) and the A block of this iteration have landed once only younger DMA groups of this wave are outstanding:
+      // W(t+1), plus the A refill issued at t-1 unless that refill is the very block needed now.
+      if (t + 1 >= nit) wait_vmcnt<0>();
+      else if (refilled_prev && !changed) wait_vmcnt<WR + HL>();
+      else wait_vmcnt<WR>();
+      __builtin_amdgcn_s_barrier();
+      // the first iteration of every block launches the DMA of the next block (if it is inside this split's range).
+      // DMA pieces of this iteration -- the next block's halo first (the counted waits above rely on that order), then
+      // W(t+2) -- are issued BETWEEN the MFMAs, where their 60-180-cycle issue cost hides under the matrix pipe.
+      const bool tail = blk >= ncb;
+      const int next_start = tail ? it + 1 : (blk + 1) * 9;
+      const bool do_refill = (t == 0 || changed) && (next_start < itb);
+      kblock(issue_w_c, do_refill, it, tail);
+      wcur = (wcur == 2) ? 0 : wcur + 1;
+      wnxt = (wnxt == 2) ? 0 : wnxt + 1;
+      refilled_prev = do_refill;
+      // advance to k-block it+1
+      changed = false;
+      if (tail) { ++blk; changed = true; }
+      else if (++tap == 9) { tap = 0; ++blk; changed = true; }
+      if (changed) abuf ^= 1;
+    }
+  };
+  const int t_steady = max(0, nit - 2);
+  run(std::true_type{}, 0, t_steady);
+  run(std::false_type{}, t_steady, nit);
 
   // ---- epilogue.  Tile row r <-> pixel (y0 + r / TW, x0 + r % TW) of image `img`.
   auto row_m = [&](int r, bool& ok) -> size_t {

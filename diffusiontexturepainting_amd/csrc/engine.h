@@ -47,7 +47,7 @@ struct Ctx;
 // A launch program: a flat list of closures bound to statically planned buffers.
 using Op = std::function<int(hipStream_t, int /*step*/)>;
 // profiling classes (dtp_profile_rows): 0-11 = gemm_kernel<BM,BN,NS> variants (id = shape + 4*(NS-2)), then the rest
-enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_COUNT = 21 };
+enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_BIG0 = 21, PK_COUNT = 25 };
 struct ProfRec {
   int kind;
   double flops, bytes;
@@ -202,6 +202,8 @@ struct Ctx {
   std::vector<ProfRec> prof;
   bool autotune = true;            // time every (tile, split-K) candidate of each distinct GEMM shape at build time
   std::map<std::string, std::pair<int, int>> tuned;  // shape key -> (tile, splits)
+  std::map<std::string, std::pair<float, float>> tune_ms;  // $DTP_TUNE_REPORT: (cold, hot) ms of the chosen configuration
+  double rep_cold_ms = 0, rep_hot_ms = 0;            // ... summed over every GEMM pushed into a program
   hipEvent_t tune_ev[2] = {nullptr, nullptr};
   void* tune_thrash = nullptr;     // 512 MiB scratch written before every timed tuning launch (cold weights)
   std::string tune_cache_path;     // $DTP_TUNE_CACHE: persisted (shape -> tile, splits) table

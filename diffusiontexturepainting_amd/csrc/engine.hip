@@ -325,12 +325,13 @@ void tune_cache_load(Ctx* c) {
   char key[256];
   int tile, splits;
   while (fscanf(f, "%255s %d %d", key, &tile, &splits) == 3)
-    if (tile >= 0 && tile < 16 && splits >= 1 && splits <= 64) c->tuned[key] = std::make_pair(tile, splits);
+    if (tile >= 0 && tile < 20 && splits >= 1 && splits <= 64) c->tuned[key] = std::make_pair(tile, splits);
   fclose(f);
   c->tune_saved = c->tuned.size();
 }
 
 void tune_cache_save(Ctx* c) {
+  if (c->rep_cold_ms > 0) fprintf(stderr, "[tune] sum over pushed GEMMs: cold %.2f ms, hot %.2f ms\n", c->rep_cold_ms, c->rep_hot_ms);
   if (c->tune_thrash) { (void)hipDeviceSynchronize(); (void)hipFree(c->tune_thrash); c->tune_thrash = nullptr; }
   if (c->tune_cache_path.empty() || c->tuned.size() == c->tune_saved) return;
   // several ranks may share the path: write a private file and rename it into place (atomic)
@@ -360,9 +361,12 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     int bt = *tile_out, bs = p.splits;
     const bool geglu = (p.flags & GF_GEGLU) != 0;
     static const int cand_splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
-    for (int tile = 0; tile < 12; ++tile) {  // 4 tile shapes x 3 pipeline depths
-      if (geglu && !((tile & 3) == 0 || (tile & 3) == 3)) continue;
-      if (p.nkb < 3 && tile >= 4) continue;
+    for (int tile = 0; tile < 20; ++tile) {  // 4 tile shapes x 3 pipeline depths, then the 256-row / 256-column tiles
+      int bm = 0, bn = 0, ns = 0;
+      if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) continue;
+      if (geglu && bn != 128) continue;
+      if (p.nkb < 3 && ns > 2) continue;
+      if ((bm == 256 && p.M < 192) || (bn == 256 && p.N < 192)) continue;
       for (int sp : cand_splits) {
         if (sp > 1 && (geglu || (p.flags & GF_LNFOLD) || p.nkb / sp < 2)) break;
         GemmParams q = p;
@@ -427,6 +431,34 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
       }
     }
     it = c->tuned.emplace(key, std::make_pair(bt, bs)).first;
+    if (getenv("DTP_TUNE_REPORT")) {  // how much of the chosen configuration's time is the cold operands?
+      GemmParams q = p;
+      if (bt >= 12 && bt < 16) q.W = p.Wcb;
+      q.kb_per_split = (p.nkb + bs - 1) / bs;
+      q.splits = (p.nkb + q.kb_per_split - 1) / q.kb_per_split;
+      q.part = c->ws;
+      q.zero = c->zero;
+      float hot = 1e30f;
+      for (int rep = 0; rep < 4; ++rep) {
+        HIP_CHECK(hipEventRecord(c->tune_ev[0], 0));
+        if (bt >= 12 && bt < 16) RC(dtp_launch_conv_halo(q, bt - 12, 0)); else RC(dtp_launch_gemm(q, bt, 0));
+        HIP_CHECK(hipEventRecord(c->tune_ev[1], 0));
+        HIP_CHECK(hipEventSynchronize(c->tune_ev[1]));
+        float t = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&t, c->tune_ev[0], c->tune_ev[1]));
+        if (rep) hot = std::min(hot, t);
+      }
+      c->tune_ms[key] = std::make_pair(best, hot);
+    }
+  }
+  {
+    auto m = c->tune_ms.find(key);
+    if (m != c->tune_ms.end()) {
+      c->rep_cold_ms += m->second.first;
+      c->rep_hot_ms += m->second.second;
+      fprintf(stderr, "[tune] %s tile=%d sp=%d cold %.1f us hot %.1f us\n", key, it->second.first, it->second.second, m->second.first * 1e3,
+              m->second.second * 1e3);
+    }
   }
   *tile_out = it->second.first;
   p.kb_per_split = (p.nkb + it->second.second - 1) / it->second.second;
@@ -439,8 +471,9 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   dtp_gemm_pick(p, &tile, c->num_cu);
   if (c->autotune) RC(tune_gemm(c, p, &tile));
   if (emit) {  // the consumer must know how many partials this launch configuration writes per row
-    static const int bn[4] = {128, 64, 64, 128};
-    emit->parts = p.splits > 1 ? 1 : (p.N + bn[tile & 3] - 1) / bn[tile & 3];
+    int bm = 0, bn = 128, ns = 0;
+    (void)dtp_gemm_tile_dims(tile, &bm, &bn, &ns);
+    emit->parts = p.splits > 1 ? 1 : (p.N + bn - 1) / bn;
     emit->M = p.M;
   }
   c->ws_need = std::max(c->ws_need, dtp_gemm_workspace_bytes(p));
@@ -453,11 +486,11 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   char lab[160];
   snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
            p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? " geglu" : "", p.stride == 2 ? " s2" : "");
-  prog_push(c, prog, tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile, 2.0 * p.M * (double)p.N * k_alg, bytes, [=](hipStream_t s, int step) {
+  prog_push(c, prog, tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile, 2.0 * p.M * (double)p.N * k_alg, bytes, [=](hipStream_t s, int step) {
     GemmParams q = p;
     q.part = c->ws;
     if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;
-    if (tile >= 12) { q.W = q.Wcb; return dtp_launch_conv_halo(q, tile - 12, s); }
+    if (tile >= 12 && tile < 16) { q.W = q.Wcb; return dtp_launch_conv_halo(q, tile - 12, s); }
     return dtp_launch_gemm(q, tile, s);
   }, lab);
   return DTP_OK;

@@ -16,6 +16,8 @@
 // up holding 4 consecutive output channels of one token -> 8-byte LDS writes into a staging
 // tile and fully coalesced 16-byte global stores with bias / residual / GEGLU fused.
 // Workgroup ids are remapped so each XCD (private L2) owns a contiguous range of tiles.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -86,7 +88,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
   const f16* w_row[WR];
 #pragma unroll
-  for (int i = 0; i < WR; ++i) w_row[i] = p.W + (size_t)(n0 + i * 32 + lrow) * p.ldw + kc;
+  for (int i = 0; i < WR; ++i) {  // packed weights have ceil(N/128)*128 rows: a 256-wide tile may reach past them
+    const int n = n0 + i * 32 + lrow;
+    w_row[i] = (BN <= 128 || n < ((p.N + 127) & ~127)) ? p.W + (size_t)n * p.ldw + kc : nullptr;
+  }
 
   int tap = 0, cch = 0, cur_tap = -1;  // conv: current tap / channel offset of this thread's chunk; tap cached in a_row[]
   if (conv) {
@@ -95,9 +100,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     else { tap = 9; cch = k - 9 * p.Cin; }  // inside the fused 1x1-shortcut tail
   }
 
-  auto issue = [&](int stage, int kb) {
-    char* As = smem + stage * STAGE;
-    char* Ws = As + BM * 128;
+  // One k-block of DMA = prep() (conv tap bookkeeping) + AR + WR "pieces" (one global_load_lds wave-instruction each,
+  // 1 KiB).  A piece costs the issuing wave 60-180 cycles, so the main loop spreads them between its MFMAs instead of
+  // issuing them back to back in front of the MFMAs.
+  size_t a_off = 0, w_off = 0;
+  auto prep = [&](int kb) {
     if (conv) {
       // The tap (ky,kx) only changes every Cin/64 k-blocks: the per-row bounds test and pixel address are
       // recomputed then and cached in a_row[]; in between only the channel offset advances.
@@ -119,20 +126,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           }
         }
       }
-#pragma unroll
-      for (int i = 0; i < AR; ++i) glds16(a_row[i] ? a_row[i] + cch : p.zero, As + (i * 32 + wave * 8) * 128);
+      a_off = (size_t)cch;
       cch += 64;
       if (tap < 9) { while (cch >= p.Cin) { cch -= p.Cin; ++tap; } }
       else if (cch >= p.Cin2) { cch -= p.Cin2; ++tap; }
     } else {
-#pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        const f16* src = a_row[i] ? a_row[i] + (size_t)kb * 64 : p.zero;
-        glds16(src, As + (i * 32 + wave * 8) * 128);
-      }
+      a_off = (size_t)kb * 64;
     }
+    w_off = (size_t)kb * 64;
+  };
+  auto piece = [&](int stage, int q) {
+    char* As = smem + stage * STAGE;
+    if (q < AR) glds16(a_row[q] ? a_row[q] + a_off : p.zero, As + (q * 32 + wave * 8) * 128);
+    else glds16((BN <= 128 || w_row[q - AR]) ? w_row[q - AR] + w_off : p.zero, As + BM * 128 + ((q - AR) * 32 + wave * 8) * 128);
+  };
+  auto issue = [&](int stage, int kb) {
+    prep(kb);
 #pragma unroll
-    for (int i = 0; i < WR; ++i) glds16(w_row[i] + (size_t)kb * 64, Ws + (i * 32 + wave * 8) * 128);
+    for (int q = 0; q < AR + WR; ++q) piece(stage, q);
   };
 
   f32x16 acc[TN][TM];
@@ -192,38 +203,85 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
   }
   int cur = 0, nxt = NS - 1;  // LDS buffer of k-block t / of k-block t+NS-1
-  for (int t = 0; t < nk; ++t) {
-    // k-block t has landed once at most `ahead` younger stages of this wave are still outstanding
-    const int ahead = min(NS - 2, nk - 1 - t);
-    if (NS == 2 || ahead <= 0) wait_vmcnt<0>();
-    else if (ahead == 1) wait_vmcnt<LOADS>();
-    else wait_vmcnt<(NS > 3 ? 2 * LOADS : LOADS)>();
-    __builtin_amdgcn_s_barrier();  // every wave's share of k-block t is in LDS; everyone finished reading k-block t-1
-    if (t + NS - 1 < nk) issue(nxt, kb0 + t + NS - 1);
+  // One k-block: all 4 k-steps' fragments are requested up front (back-to-back ds_read_b128), then each step's MFMAs start
+  // as soon as ITS operands have arrived (LDS returns in order; hand-counted lgkmcnt, see common.h).  The DMA pieces of
+  // k-block t+NS-1 are issued BETWEEN the MFMAs (1-2 per k-step), where their issue cost hides under the matrix pipe.
+  auto kblock = [&](auto issue_c) {
+    constexpr bool ISSUE = decltype(issue_c)::value;
+    constexpr int NM = TM * TN, NP = AR + WR;
     const char* As = smem + cur * STAGE;
     const char* Ws = As + BM * 128;
-    cur = (cur + 1 == NS) ? 0 : cur + 1;
-    nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    // fragments of k-step ks live in fr[ks % LA]: [0,TM) activations, [TM,TM+TN) weights; LA k-steps are in flight
+    constexpr int NF = TM + TN, LA = (4 * NF <= 16) ? 4 : 2, PPS = (NP + 3) / 4;
+    f16x8 fr[LA][NF];
+    const uint32_t a_lds = lds_addr(As), w_lds = lds_addr(Ws);
+    auto read_step = [&](int ks) {
       const int c = ks * 2 + fhalf;
-      f16x8 af[TM], wf[TN];
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int row = wm0 + j * 32 + frow;
-        af[j] = *(const f16x8*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        fr[ks % LA][j] = lds_read16(a_lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int row = wn0 + i * 32 + frow;
-        wf[i] = *(const f16x8*)(Ws + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        fr[ks % LA][TM + i] = lds_read16(w_lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
       }
+    };
+    // depth 2 has no slack for a late DMA (the next iteration waits for vmcnt(0)): issue its pieces first, as a block;
+    // the deeper rings spread them between the MFMAs
+    constexpr bool SPREAD = NS > 2;
+    if constexpr (ISSUE && !SPREAD) {
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+      for (int q = 0; q < NP; ++q) piece(nxt, q);
+      __builtin_amdgcn_sched_barrier(0);
     }
-  }
+#pragma unroll
+    for (int ks = 0; ks < LA; ++ks) read_step(ks);
+#define DTP_PIECE(q)                                                                                        \
+    if constexpr (ISSUE && SPREAD && (q) < NP) {                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      piece(nxt, (q));                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+#define DTP_MMA_STEP(ks)                                                                                    \
+    {                                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      wait_lds_frags<((ks + LA < 4 ? ks + LA : 4) - ks - 1) * NF, NF>(fr[ks % LA]);                         \
+      _Pragma("unroll") for (int i = 0; i < TN; ++i) _Pragma("unroll") for (int j = 0; j < TM; ++j) {       \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[ks % LA][TM + i], fr[ks % LA][j], acc[i][j], 0, 0, 0); \
+        if constexpr (PPS >= 1) { if (i * TM + j == 0) { DTP_PIECE(ks * PPS) } }                            \
+        if constexpr (PPS >= 2) { if (i * TM + j == NM / PPS) { DTP_PIECE(ks * PPS + 1) } }                 \
+        if constexpr (PPS >= 3) { if (i * TM + j == 2 * NM / PPS) { DTP_PIECE(ks * PPS + 2) } }             \
+      }                                                                                                     \
+      if constexpr (ks + LA < 4) {                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        read_step(ks + LA);                                                                                 \
+      }                                                                                                     \
+    }
+    DTP_MMA_STEP(0) DTP_MMA_STEP(1) DTP_MMA_STEP(2) DTP_MMA_STEP(3)
+#undef DTP_MMA_STEP
+#undef DTP_PIECE
+  };
+  // Two loops (steady state with DMA, then the last NS-1 k-blocks without) rather than one loop with both bodies: with
+  // both in one loop the compiler shuffles the 64 accumulator registers between AGPRs and VGPRs on every iteration.
+  auto run = [&](auto issue_c, int t_begin, int t_end) {
+    for (int t = t_begin; t < t_end; ++t) {
+      // k-block t has landed once at most `ahead` younger stages of this wave are still outstanding
+      const int ahead = min(NS - 2, nk - 1 - t);
+      if (NS == 2 || ahead <= 0) wait_vmcnt<0>();
+      else if (ahead == 1) wait_vmcnt<LOADS>();
+      else wait_vmcnt<(NS > 3 ? 2 * LOADS : LOADS)>();
+      __builtin_amdgcn_s_barrier();  // every wave's share of k-block t is in LDS; everyone finished reading k-block t-1
+      if constexpr (decltype(issue_c)::value) prep(kb0 + t + NS - 1);
+      kblock(issue_c);
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+      nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+    }
+  };
+  const int t_steady = max(0, nk - (NS - 1));
+  run(std::true_type{}, 0, t_steady);
+  run(std::false_type{}, t_steady, nk);
 
   // ---------------------------------------------------------------- epilogue
   // D layout (32x32): lane holds column (lane&31) = token, rows (r&3)+8*(r>>2)+4*(lane>>5) = channel.
@@ -453,8 +511,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
 template <int BM, int BN, int NS>
 int launch_tile(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  constexpr int lds = NS * (BM + BN) * 128 + 1024;  // + per-row LayerNorm statistics
-  static_assert(lds - 1024 >= BM * (BN + 8) * 2, "staging tile must fit in the pipeline buffers");
+  constexpr int lds = NS * (BM + BN) * 128 + BM * 8;  // + per-row LayerNorm statistics
+  static_assert(lds - BM * 8 >= BM * (BN + 8) * 2, "staging tile must fit in the pipeline buffers");
   static_assert(lds <= 160 * 1024, "LDS budget");
   hipLaunchKernelGGL((gemm_kernel<BM, BN, NS>), dim3(tiles, 1, p.splits), dim3(256), lds, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
@@ -464,13 +522,23 @@ int launch_tile(const GemmParams& p, hipStream_t s) {
 
 #define FOR_ALL_VARIANTS(X) \
   X(128, 128, 2) X(128, 128, 3) X(128, 128, 4) X(128, 64, 2) X(128, 64, 3) X(128, 64, 4) \
-  X(64, 64, 2) X(64, 64, 3) X(64, 64, 4) X(64, 128, 2) X(64, 128, 3) X(64, 128, 4)
+  X(64, 64, 2) X(64, 64, 3) X(64, 64, 4) X(64, 128, 2) X(64, 128, 3) X(64, 128, 4) \
+  X(256, 128, 2) X(256, 128, 3) X(128, 256, 2) X(128, 256, 3)
 
 void dtp_gemm_init() {  // raise the dynamic-LDS limit once, outside any stream capture
 #define SET_ATTR(BM, BN, NS) \
-  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + 1024);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8);
   FOR_ALL_VARIANTS(SET_ATTR)
 #undef SET_ATTR
+}
+
+// tile id -> (BM, BN, pipeline depth).  0..11: shape (id & 3) of {128x128, 128x64, 64x64, 64x128} at depth 2 + id / 4;
+// 16..19: the big tiles {256x128, 256x128, 128x256, 128x256} at depth {2, 3, 2, 3}.  (12..15 are the halo conv kernels.)
+bool dtp_gemm_tile_dims(int tile, int* bm, int* bn, int* ns) {
+  static const int sm[4] = {128, 128, 64, 64}, sn[4] = {128, 64, 64, 128};
+  if (tile >= 0 && tile < 12) { *bm = sm[tile & 3]; *bn = sn[tile & 3]; *ns = 2 + (tile >> 2); return true; }
+  if (tile >= 16 && tile < 20) { *bm = tile < 18 ? 256 : 128; *bn = tile < 18 ? 128 : 256; *ns = 2 + (tile & 1); return true; }
+  return false;
 }
 
 size_t dtp_gemm_workspace_bytes(const GemmParams& p) {
@@ -519,18 +587,15 @@ int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
     dtp_set_error("gemm: LayerNorm fold needs a dense, unsplit GEMM with lns");
     return DTP_ERR_ARG;
   }
-  if ((p.flags & GF_GEGLU) && (p.splits > 1 || !((tile & 3) == 0 || (tile & 3) == 3) || (p.N % 128))) {
+  int bm = 0, bn = 0, ns = 0;
+  if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) { dtp_set_error("gemm: bad tile id %d", tile); return DTP_ERR_ARG; }
+  if ((p.flags & GF_GEGLU) && (p.splits > 1 || bn != 128 || (p.N % 128))) {
     dtp_set_error("gemm: GEGLU needs a 128-wide N tile, N %% 128 == 0 and no split-K");
     return DTP_ERR_ARG;
   }
   int rc = -1;
-  // variant id = tile + 4 * (stages - 2): tile 0..3 as documented, stages 2..4
-  const int shape = tile & 3, ns = 2 + (tile >> 2);
-  if (tile < 0 || tile >= 12) { dtp_set_error("gemm: bad tile id %d", tile); return DTP_ERR_ARG; }
 #define DISPATCH(BM, BN, NS) \
-  if (rc < 0 && ns == NS && ((BM == 128 && BN == 128 && shape == 0) || (BM == 128 && BN == 64 && shape == 1) || \
-                             (BM == 64 && BN == 64 && shape == 2) || (BM == 64 && BN == 128 && shape == 3)))       \
-    rc = launch_tile<BM, BN, NS>(p, s);
+  if (rc < 0 && bm == BM && bn == BN && ns == NS) rc = launch_tile<BM, BN, NS>(p, s);
   FOR_ALL_VARIANTS(DISPATCH)
 #undef DISPATCH
   if (rc != DTP_OK) { dtp_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError())); return rc; }

@@ -106,7 +106,8 @@ int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes);
  * the stream it runs on (graph replay is bypassed); dtp_profile_rows() aggregates them per kernel
  * class: kind 0-11 = gemm_kernel<BM,BN,NS> (the implicit-GEMM kernel; id = shape + 4*(NS-2), shape 0..3 =
  * 128x128 / 128x64 / 64x64 / 64x128), 12 = attention_kernel, 13 = GroupNorm (stats+apply or fused),
- * 14 = layernorm, 15 = concat/elementwise, 16 = softmax_rows.  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
+ * 14 = layernorm, 15 = concat/elementwise, 16 = softmax_rows, 17-20 = conv_halo_kernel<8,16,64> / <8,16,128> / <8,8,64> /
+ * <8,8,128> (halo-tiled 3x3 conv), 21-24 = gemm_kernel<256,128,2> / <256,128,3> / <128,256,2> / <128,256,3>.  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
  * dtp_profile(ctx, 0) switches back to graph replay.  The nvtx/cudaEvent hooks of
  * stable_diffusion_pipeline.py:146-149,486-503 are the reference counterpart. */
 typedef struct { int kind; int launches; double ms; double flops; double bytes; } dtp_prof_row;
@@ -132,7 +133,8 @@ typedef struct {
   int conv, Hi, Wi, Ho, Wo, Cin, stride, pad, upsample2x;
   int flags;         /* DTP_GF_* */
   int tile;          /* -1 = heuristic; gemm_kernel: shape + 4*(stages-2), shape 0:128x128 1:128x64 2:64x64 3:64x128 (MxN),
-                        stages 2..4; 12..15 = conv_halo_kernel (8x16|8x8 pixel tile) x (64|128 channels), needs Wcb */
+                        stages 2..4; 12..15 = conv_halo_kernel (8x16|8x8 pixel tile) x (64|128 channels), needs Wcb;
+                        16..19 = gemm_kernel 256x128 (2|3 stages), 128x256 (2|3 stages) */
   int splits;        /* 0 = heuristic; >=1 = forced split-K factor */
   const float* lns;  /* DTP_GF_LNFOLD: row sums of the packed weights (dtp_op_rowsum) */
   float ln_eps;

@@ -36,7 +36,7 @@ def close(got, ref, tol=2e-3):
 
 
 @pytest.mark.parametrize("m,n,k", [(300, 320, 320), (4096, 640, 1280), (192, 1280, 2560), (77, 768, 768), (14, 1280, 768)])
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])  # shape + 4 * (pipeline stages - 2)
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19])  # shape + 4 * (stages - 2); 16.. = 256-wide tiles
 def test_gemm_dense(ops, m, n, k, tile):
     a, w = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5)
     bias = torch.randn(n, generator=torch.Generator().manual_seed(3))
@@ -91,7 +91,7 @@ def test_gemm_geglu(ops, m, c):
 
 
 @pytest.mark.parametrize("m,c,n,tile,geglu", [(300, 320, 960, -1, False), (100, 1280, 1280, 6, False), (513, 640, 5120, -1, True),
-                                             (64, 768, 768, 3, False)])
+                                             (64, 768, 768, 3, False), (513, 640, 5120, 17, True), (300, 320, 960, 18, False)])
 def test_gemm_layernorm_fold(ops, m, c, n, tile, geglu):
     """LN(x) W^T + b computed from the RAW x: W carries gamma, bias carries W.beta, statistics in-kernel."""
     from diffusiontexturepainting_amd._lib import GF_BIAS, GF_GEGLU
@@ -147,7 +147,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [-1, 5, 8, 10])
+@pytest.mark.parametrize("tile", [-1, 5, 8, 10, 16, 19])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3x3(ops, case, tile):
     b, h, w, cin, cout, stride, pad, ups, out_hw = case
@@ -170,7 +170,8 @@ def test_conv3x3(ops, case, tile):
     close(got, ref)
 
 
-@pytest.mark.parametrize("b,h,cin,cin2,cout,tile,splits", [(2, 16, 64, 128, 64, -1, 0), (3, 8, 320, 640, 320, 5, 0), (1, 8, 128, 64, 256, 8, 3)])
+@pytest.mark.parametrize("b,h,cin,cin2,cout,tile,splits", [(2, 16, 64, 128, 64, -1, 0), (3, 8, 320, 640, 320, 5, 0), (1, 8, 128, 64, 256, 8, 3),
+                                                           (3, 16, 320, 640, 320, 17, 2), (1, 16, 128, 64, 256, 18, 0)])
 def test_conv3x3_fused_shortcut(ops, b, h, cin, cin2, cout, tile, splits):
     """ResBlock tail as ONE contraction: conv3x3(t) + conv1x1(x) + biases = [im2col(t) | x] . [W3 | W1]^T."""
     t, x = rnd(b, h, h, cin, seed=24), rnd(b, h, h, cin2, seed=25)
