@@ -38,10 +38,13 @@ class GemmDesc(C.Structure):
                 ("conv", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Cin", C.c_int),
                 ("stride", C.c_int), ("pad", C.c_int), ("upsample2x", C.c_int),
                 ("flags", C.c_int), ("tile", C.c_int), ("splits", C.c_int), ("lns", C.c_void_p), ("ln_eps", C.c_float),
-                ("A2", C.c_void_p), ("lda2", C.c_int), ("Cin2", C.c_int), ("Wcb", C.c_void_p)]
+                ("A2", C.c_void_p), ("lda2", C.c_int), ("Cin2", C.c_int), ("Wcb", C.c_void_p),
+                ("batch", C.c_int), ("a_bs", C.c_int64), ("w_bs", C.c_int64), ("c_bs", C.c_int64), ("r_bs", C.c_int64),
+                ("bias_bs", C.c_int), ("lns_bs", C.c_int), ("sm_valid", C.c_int)]
 
 
 GF_BIAS, GF_BIAS_M, GF_RESID, GF_GEGLU, GF_GELU, GF_QUICKGELU, GF_OUT_F32, GF_SILU, GF_LNFOLD = 1, 2, 4, 8, 64, 128, 256, 512, 1024
+GF_SOFTMAX16 = 4096
 
 # every symbol include/dtp.h declares: name -> (restype, argtypes)
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64

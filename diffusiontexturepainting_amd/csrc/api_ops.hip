@@ -75,11 +75,13 @@ int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s) {
   p.flags = d->flags | (d->conv ? GF_CONV3 : 0) | (d->upsample2x ? GF_UPS2 : 0);
   p.lns = d->lns; p.ln_eps = d->ln_eps;
   p.A2 = (const f16*)d->A2; p.lda2 = d->lda2; p.Cin2 = d->Cin2;
+  p.batch = d->batch; p.a_bs = d->a_bs; p.w_bs = d->w_bs; p.c_bs = d->c_bs; p.r_bs = d->r_bs;
+  p.bias_bs = d->bias_bs; p.lns_bs = d->lns_bs; p.sm_valid = d->sm_valid;
   if (p.ldw < p.nkb * 64) { dtp_set_error("gemm: ldw=%d smaller than padded K=%d", p.ldw, p.nkb * 64); return DTP_ERR_ARG; }
   int tile = 0;
   dtp_gemm_pick(p, &tile, g_ops.num_cu);
   if (d->tile >= 0) tile = d->tile;
-  if (d->splits >= 1) {
+  if (d->splits >= 1 && d->batch <= 1) {
     p.kb_per_split = (p.nkb + d->splits - 1) / d->splits;
     p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
   }

@@ -72,6 +72,7 @@ enum {
   GF_LNFOLD = 1024,  // A is the RAW pre-LayerNorm tensor; W carries gamma, bias carries W.beta; row statistics come from
                      // the producer (st_in) or are computed in-kernel; out = rstd*(acc - mean*lns[n]) + bias[n]
   GF_ROWSTATS = 2048,// also emit per-row (sum, sum of squares) of the fp16 output, one partial per N tile -> st_out
+  GF_SOFTMAX16 = 4096,// epilogue: softmax over each aligned group of 16 output columns (first sm_valid of them; the rest -> 0)
   GF_MFAST = 1 << 20,// internal: tile_m varies fastest (neighbouring workgroups share the W panel)
 };
 
@@ -98,6 +99,12 @@ struct GemmParams {
   const f16* A2;     // CONV3 only: a 10th, dense "tap" appended to K -- the ResBlock's 1x1 shortcut conv, read from the
   int lda2, Cin2;    // block input [M][lda2] (Cin2 channels, multiple of 64); null / 0 = none
   int flags;
+  // batched (grouped) problems: grid.y = batch; problem b uses A + b*a_bs, W + b*w_bs, C + b*c_bs, R + b*r_bs (elements),
+  // bias + b*bias_bs, lns + b*lns_bs.  Row statistics stay indexed by the global row b*M + m of a [parts][st_rows][2] array.
+  int batch;         // 0/1 = plain GEMM
+  long long a_bs, w_bs, c_bs, r_bs;
+  int bias_bs, lns_bs, st_rows;
+  int sm_valid;      // GF_SOFTMAX16: valid columns per group of 16
 };
 
 // tile: shape + 4 * (stages - 2); shape 0 = 128x128, 1 = 128(M)x64(N), 2 = 64x64, 3 = 64(M)x128(N); stages 2..4
@@ -138,6 +145,9 @@ int dtp_launch_pack_linear_weight(const float* w, f16* out, int N, int K, int ld
 int dtp_launch_rowdot(const float* w, const float* v, float* out, int N, int K, hipStream_t s);
 int dtp_launch_scale_cols(float* w, const float* g, int N, int K, hipStream_t s);
 int dtp_launch_rowsum_f16(const f16* w, int ld, int K, float* out, int rows, hipStream_t s);
+int dtp_launch_expand_kv(const f16* kv, f16* kexp, f16* vexp, int N, int T, int C, int H, float scale, hipStream_t s);
+int dtp_launch_transpose_f16(const f16* src, int lds_, f16* dst, int ldd, int rows, int cols, hipStream_t s);
+int dtp_launch_rowdot_f16(const f16* a, int ld, const float* v, float* out, int rows, int K, hipStream_t s);
 // conv_halo.hip: variant 0..3 = (8x16|8x8 pixel tile) x (64|128 output channels); kb_per_split counts 64-channel blocks
 bool dtp_conv_halo_supported(const GemmParams& p);
 int dtp_launch_conv_halo(const GemmParams& p, int variant, hipStream_t s);

@@ -131,6 +131,55 @@ inline int grid_for(long long total) {
   return (int)b;
 }
 
+
+// ---- cross-attention against a short context, algebraically fused (unet.hip transformer()):
+// kv [N][T][2C] (K | V of the context tokens) -> Kexp / Vexp [N*H*16][C]: row (n, h, j) holds token j's K (times
+// `scale`) / V restricted to the channels of head h, zero elsewhere and for j >= T.  Kexp . Wq'^T and Wo . Vexp^T are then
+// ordinary GEMMs that give, per sample, the [H*16][C] score matrix and the [C][H*16] value-output matrix.
+__global__ __launch_bounds__(256) void expand_kv_kernel(const f16* __restrict__ kv, f16* __restrict__ kexp, f16* __restrict__ vexp, int N,
+                                                        int T, int C, int H, float scale) {
+  const long long total = (long long)N * H * 16 * (C / 8);
+  const int dh = C / H, c8 = C / 8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ch = (int)(i % c8) * 8;
+    const long long row = i / c8;  // (n*H + h)*16 + j
+    const int j = (int)(row & 15), h = (int)((row >> 4) % H), n = (int)(row / (16 * H));
+    f16x8 ko = {0, 0, 0, 0, 0, 0, 0, 0}, vo = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (j < T && ch / dh == h) {  // dh % 8 == 0: a chunk never straddles two heads
+      const f16* src = kv + ((size_t)n * T + j) * 2 * C + ch;
+      const f16x8 kk = *(const f16x8*)src;
+      vo = *(const f16x8*)(src + C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ko[e] = (f16)((float)kk[e] * scale);
+    }
+    *(f16x8*)(kexp + row * C + ch) = ko;
+    *(f16x8*)(vexp + row * C + ch) = vo;
+  }
+}
+
+__global__ __launch_bounds__(256) void transpose_f16_kernel(const f16* __restrict__ src, int lds_, f16* __restrict__ dst, int ldd, int rows,
+                                                            int cols) {
+  __shared__ f16 t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8)
+    t[r][tx] = (by + r < rows && bx + tx < cols) ? src[(size_t)(by + r) * lds_ + bx + tx] : (f16)0.f;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (bx + r < cols && by + tx < rows) dst[(size_t)(bx + r) * ldd + by + tx] = t[tx][r];
+}
+
+// out[r] = sum_k a[r][k] * v[k]  (fp16 rows, fp32 vector), one wave per row
+__global__ __launch_bounds__(256) void rowdot_f16_kernel(const f16* __restrict__ a, int ld, const float* __restrict__ v, float* __restrict__ out,
+                                                         int rows, int K) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += (float)a[(size_t)r * ld + k] * v[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[r] = s;
+}
+
 }  // namespace
 
 #define LAUNCH_RET() return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP
@@ -174,6 +223,19 @@ int dtp_launch_touch(const void* p, size_t bytes, float* sink, hipStream_t s) {
   LAUNCH_RET();
 }
 
+int dtp_launch_expand_kv(const f16* kv, f16* kexp, f16* vexp, int N, int T, int C, int H, float scale, hipStream_t s) {
+  if (C % (8 * H) || T > 16) { dtp_set_error("expand_kv: needs C %% (8*heads) == 0 and <= 16 tokens"); return DTP_ERR_ARG; }
+  hipLaunchKernelGGL(expand_kv_kernel, dim3(grid_for((long long)N * H * 16 * (C / 8))), dim3(256), 0, s, kv, kexp, vexp, N, T, C, H, scale);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
+int dtp_launch_transpose_f16(const f16* src, int lds_, f16* dst, int ldd, int rows, int cols, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_f16_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, src, lds_, dst, ldd, rows, cols);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
+int dtp_launch_rowdot_f16(const f16* a, int ld, const float* v, float* out, int rows, int K, hipStream_t s) {
+  hipLaunchKernelGGL(rowdot_f16_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, a, ld, v, out, rows, K);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
 int dtp_launch_rowdot(const float* w, const float* v, float* out, int N, int K, hipStream_t s) {
   hipLaunchKernelGGL(rowdot_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w, v, out, N, K);
   LAUNCH_RET();

@@ -72,6 +72,7 @@ struct XfW {
   NormW gn, ln1, ln2, ln3;
   ConvW proj_in, qkv, out1, q2, kv2, out2, ff1, ff2, proj_out;
   int kv_index = -1;  // which cross-attention K/V buffer
+  f16* q2T = nullptr; // LayerNorm-folded to_q of the cross-attention, transposed and packed: [up(C,128)][C] (rows = input channel)
 };
 struct VaeAttnW {
   NormW gn;
@@ -130,6 +131,13 @@ struct UNetProg {
   f16* ctx16 = nullptr;    // [N][14][768]
   float* out32 = nullptr;  // [N][h][w][4]
   std::vector<f16*> kvbuf; // 16 x [N*14][2C]
+  // Cross-attention against the 14 context tokens, fused algebraically: per sample n and block i
+  //   xW1[i][n] [8*16][C]   = (scale * K_n,h,j restricted to head h) . Wq'      scores = LN2(x) . xW1^T   (+ xb1, LN fold via xl1)
+  //   xW2[i][n] [C][8*16]   = Wo . (V_n,h,j restricted to head h)^T              out    = softmax_j(scores) . xW2^T + bo + x
+  // both recomputed once per stamp by the `kv` program; the per-evaluation work is two small grouped GEMMs per block.
+  std::vector<f16*> xW1, xW2;
+  std::vector<float*> xb1, xl1;
+  f16 *kexp = nullptr, *vexp = nullptr;  // scratch [N*128][1280]
 };
 struct VaeEncProg {
   int B = 0;
@@ -235,6 +243,8 @@ struct RowStats {
 };
 
 // ---- builder helpers (engine.hip): every function appends ops to `prog` and returns planned buffers
+int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg, RowStats* emit = nullptr);
+
 struct Builder {
   Ctx* c;
   Prog* prog;

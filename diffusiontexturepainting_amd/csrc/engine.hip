@@ -349,8 +349,9 @@ void tune_cache_save(Ctx* c) {
 // with every tile variant x split-K factor on the real buffers and the fastest pair is kept.
 static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   char key[200];
-  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin, p.stride,
-           p.lda, p.ldc, p.ldw, p.st_parts, p.Cin2, p.lda2);
+  int kl = snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
+                    p.stride, p.lda, p.ldc, p.ldw, p.st_parts, p.Cin2, p.lda2);
+  if (p.batch > 1) snprintf(key + kl, sizeof(key) - kl, ",b%d", p.batch);
   auto it = c->tuned.find(key);
   if (it == c->tuned.end()) {
     if (!c->tune_ev[0]) { HIP_CHECK(hipEventCreate(&c->tune_ev[0])); HIP_CHECK(hipEventCreate(&c->tune_ev[1])); }
@@ -368,7 +369,7 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
       if (p.nkb < 3 && ns > 2) continue;
       if ((bm == 256 && p.M < 192) || (bn == 256 && p.N < 192)) continue;
       for (int sp : cand_splits) {
-        if (sp > 1 && (geglu || (p.flags & GF_LNFOLD) || p.nkb / sp < 2)) break;
+        if (sp > 1 && (geglu || (p.flags & GF_LNFOLD) || p.batch > 1 || p.nkb / sp < 2)) break;
         GemmParams q = p;
         q.kb_per_split = (p.nkb + sp - 1) / sp;
         q.splits = (p.nkb + q.kb_per_split - 1) / q.kb_per_split;
@@ -466,7 +467,7 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   return DTP_OK;
 }
 
-int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg, RowStats* emit = nullptr) {
+int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg, RowStats* emit) {
   int tile = 0;
   dtp_gemm_pick(p, &tile, c->num_cu);
   if (c->autotune) RC(tune_gemm(c, p, &tile));
@@ -474,7 +475,7 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
     int bm = 0, bn = 128, ns = 0;
     (void)dtp_gemm_tile_dims(tile, &bm, &bn, &ns);
     emit->parts = p.splits > 1 ? 1 : (p.N + bn - 1) / bn;
-    emit->M = p.M;
+    emit->M = p.M * (p.batch > 1 ? p.batch : 1);
   }
   c->ws_need = std::max(c->ws_need, dtp_gemm_workspace_bytes(p));
   p.zero = c->zero;
@@ -482,11 +483,13 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   const double n_out = (p.flags & GF_GEGLU) ? p.N / 2.0 : (double)p.N;
   const double a_elems = (p.flags & GF_CONV3) ? (double)p.M * (k_alg / 9.0) * ((p.flags & GF_UPS2) ? 0.25 : (double)(p.stride * p.stride))
                                                : (double)p.M * k_alg;
-  const double bytes = 2.0 * (a_elems + (double)p.N * k_alg + (double)p.M * n_out);
+  const double nb = p.batch > 1 ? (double)p.batch : 1.0;
+  const double bytes = 2.0 * nb * (a_elems + (double)p.N * k_alg + (double)p.M * n_out);
   char lab[160];
-  snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
-           p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? " geglu" : "", p.stride == 2 ? " s2" : "");
-  prog_push(c, prog, tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile, 2.0 * p.M * (double)p.N * k_alg, bytes, [=](hipStream_t s, int step) {
+  snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
+           p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? " geglu" : "", p.stride == 2 ? " s2" : "",
+           p.batch > 1 ? (" x" + std::to_string(p.batch)).c_str() : "");
+  prog_push(c, prog, tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile, 2.0 * nb * p.M * (double)p.N * k_alg, bytes, [=](hipStream_t s, int step) {
     GemmParams q = p;
     q.part = c->ws;
     if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;

@@ -35,7 +35,18 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // NS = LDS pipeline depth: the DMA of k-block t+NS-1 is issued while k-block t is multiplied; the wait
 // before the (raw) barrier is a COUNTED vmcnt so NS-2 younger stages stay in flight across it.
 template <int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
+  GemmParams p = pin;
+  const int st_rows = p.st_rows > 0 ? p.st_rows : p.M;
+  const int st_m0 = (p.batch > 1) ? (int)blockIdx.y * p.M : 0;
+  if (p.batch > 1) {  // grouped problems: one per blockIdx.y
+    const long long bz = blockIdx.y;
+    p.A += bz * p.a_bs; p.W += bz * p.w_bs;
+    p.C = (p.flags & GF_OUT_F32) ? (void*)((float*)p.C + bz * p.c_bs) : (void*)((f16*)p.C + bz * p.c_bs);
+    if (p.R) p.R += bz * p.r_bs;
+    if (p.bias) p.bias += bz * p.bias_bs;
+    if (p.lns) p.lns += bz * p.lns_bs;
+  }
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA blocks per wave along M / N
   constexpr int AR = BM / 32, WR = BN / 32;  // DMA wave-instructions per wave per k-block
   constexpr int STAGE = (BM + BN) * 128;
@@ -172,8 +183,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       float s1 = 0.f, s2 = 0.f;
       if (m < p.M)
         for (int q = 0; q < p.st_parts; ++q) {
-          s1 += p.st_in[((size_t)q * p.M + m) * 2];
-          s2 += p.st_in[((size_t)q * p.M + m) * 2 + 1];
+          s1 += p.st_in[((size_t)q * st_rows + st_m0 + m) * 2];
+          s2 += p.st_in[((size_t)q * st_rows + st_m0 + m) * 2 + 1];
         }
       const float mean = s1 / (float)p.K;
       rowst[2 * r] = mean;
@@ -425,6 +436,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = x[e] / (1.0f + __expf(-x[e]));
       }
+      if (fl & GF_SOFTMAX16) {  // a group = two adjacent 8-column chunks = this lane and lane ^ 1 (N % 16 == 0: both active)
+        const int half = (nc & 1) * 8;
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (half + e < p.sm_valid) mx = fmaxf(mx, x[e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { x[e] = (half + e < p.sm_valid) ? __expf(x[e] - mx) : 0.f; sum += x[e]; }
+        sum += __shfl_xor(sum, 1);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] *= inv;
+      }
       if (full && vec_ok) {
         if (fl & GF_RESID) {
           const f16x8 r = *(const f16x8*)(p.R + (size_t)m * p.ldr + n);
@@ -458,8 +483,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int o = NC / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
       if (nc == 0 && m < p.M) {
-        p.st_out[((size_t)tile_n * p.M + m) * 2] = s1;
-        p.st_out[((size_t)tile_n * p.M + m) * 2 + 1] = s2;
+        p.st_out[((size_t)tile_n * st_rows + st_m0 + m) * 2] = s1;
+        p.st_out[((size_t)tile_n * st_rows + st_m0 + m) * 2 + 1] = s2;
       }
     }
   }
@@ -514,7 +539,7 @@ int launch_tile(const GemmParams& p, hipStream_t s) {
   constexpr int lds = NS * (BM + BN) * 128 + BM * 8;  // + per-row LayerNorm statistics
   static_assert(lds - BM * 8 >= BM * (BN + 8) * 2, "staging tile must fit in the pipeline buffers");
   static_assert(lds <= 160 * 1024, "LDS budget");
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS>), dim3(tiles, 1, p.splits), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS>), dim3(tiles, p.batch > 1 ? p.batch : 1, p.splits), dim3(256), lds, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
@@ -554,9 +579,9 @@ void dtp_gemm_pick(GemmParams& p, int* tile, int num_cu) {
   if (p.N <= 64 && p.M >= 512) t = 1;
   if (geglu) t = (p.M >= 512) ? 0 : 3;
   static const int bm[4] = {128, 128, 64, 64}, bn[4] = {128, 64, 64, 128};
-  const long long blocks = (long long)((p.M + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]);
+  const long long blocks = (long long)((p.M + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]) * (p.batch > 1 ? p.batch : 1);
   int splits = 1;
-  if (!geglu && !(p.flags & GF_LNFOLD) && blocks * 2 <= num_cu && p.nkb >= 8) {
+  if (!geglu && !(p.flags & GF_LNFOLD) && p.batch <= 1 && blocks * 2 <= num_cu && p.nkb >= 8) {
     splits = (int)((2LL * num_cu + blocks - 1) / blocks);
     if (splits > p.nkb / 4) splits = p.nkb / 4;
     if (splits > 32) splits = 32;
@@ -577,6 +602,12 @@ int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
   if ((p.flags & GF_CONV3) && (p.Cin & 7)) { dtp_set_error("conv: Cin must be a multiple of 8"); return DTP_ERR_ARG; }
   if (p.A2 && (!(p.flags & GF_CONV3) || ((9 * p.Cin) & 63) || (p.Cin2 & 63) || (p.lda2 & 7) || p.stride != 1)) {
     dtp_set_error("conv: fused shortcut tail needs stride 1 and 9*Cin, Cin2 multiples of 64");
+    return DTP_ERR_ARG;
+  }
+  if (p.batch > 1 && (p.splits > 1 || (p.flags & GF_CONV3))) { dtp_set_error("gemm: batched problems are dense and unsplit"); return DTP_ERR_ARG; }
+  if ((p.flags & GF_SOFTMAX16) && ((p.N & 15) || p.splits > 1 || p.sm_valid < 1 || p.sm_valid > 16 || (p.ldc & 7) ||
+                                   (p.flags & (GF_GEGLU | GF_OUT_F32 | GF_RESID | GF_ROWSTATS)))) {
+    dtp_set_error("gemm: the group-softmax epilogue needs N %% 16 == 0, fp16 output, no split-K / residual / row statistics");
     return DTP_ERR_ARG;
   }
   if ((p.flags & GF_ROWSTATS) && (!p.st_out || (p.flags & (GF_GEGLU | GF_OUT_F32)))) {

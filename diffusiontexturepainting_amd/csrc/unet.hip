@@ -40,6 +40,14 @@ static int load_xf(Ctx* c, const std::string& p, XfW& w, int& kv_counter) {
   RC(load_linear(c, {t + ".ff.net.2"}, w.ff2, true));
   RC(load_conv(c, p + ".proj_out", w.proj_out));
   w.kv_index = kv_counter++;
+  {  // transposed copy of the folded to_q for the per-stamp score-matrix GEMM (rows = input channel, K = output channel)
+    const int C = w.q2.K, rows = (C + 127) / 128 * 128, ld = (C + 63) / 64 * 64;
+    void* pq;
+    RC(ctx_arena_alloc(c, (size_t)rows * ld * 2, &pq));
+    HIP_CHECK(hipMemsetAsync(pq, 0, (size_t)rows * ld * 2, 0));
+    w.q2T = (f16*)pq;
+    RC(dtp_launch_transpose_f16(w.q2.w, w.q2.ldw, w.q2T, ld, w.q2.cout, C, 0));
+  }
   return DTP_OK;
 }
 
@@ -157,7 +165,7 @@ int ensure_temb(Ctx* c, const std::vector<float>& timesteps) {
 
 static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up, T& out, const T* dst = nullptr) {
   const int C = x.C, S = x.H * x.W, N = x.B;
-  T t, y, n1, qkv, a, y2, n2, q2, a2, y3, n3, f, y4;
+  T t, y, n1, qkv, a, y2, n2, y3, n3, f, y4;
   RC(b.gn(x, w.gn, 1e-6f, false, t));
   // LayerNorms are folded into their consumer GEMMs; the row statistics ride on the producer's epilogue
   RowStats st1, st2, st3;
@@ -175,17 +183,34 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
   RC(b.alloc_stats(x.rows(), C, st2));
   RC(b.linear(a, w.out1, &y, 0, y2, &st2));
   b.release(a); b.release(y);
-  RC(b.linear(y2, w.q2, nullptr, 0, q2, nullptr, &st2));  // LN2 folded
-  b.release_stats(st2);
-  T kk, vv;
-  kk.p = up.kvbuf[w.kv_index]; kk.B = N; kk.H = 1; kk.W = 14; kk.C = C; kk.ld = 2 * C;
-  vv = kk; vv.p += C;
-  RC(b.attention(q2, kk, vv, 8, S, 14, N, a2));
-  b.release(q2);
-  a2.B = x.B; a2.H = x.H; a2.W = x.W;
-  RC(b.alloc_stats(x.rows(), C, st3));
-  RC(b.linear(a2, w.out2, &y2, 0, y3, &st3));
-  b.release(a2); b.release(y2);
+  // Cross-attention over 14 context tokens: softmax_j(LN2(y2) Wq'^T K^T) V Wo^T collapses to two grouped GEMMs against
+  // per-sample matrices prepared once per stamp (UNetProg::xW1 / xW2): scores + group softmax, then the value-output product.
+  {
+    const int i = w.kv_index, Cp = (C + 127) / 128 * 128;
+    T pm = b.alloc(x.B, x.H, x.W, 128);  // probabilities [rows][8 heads x 16 (14 valid)]
+    if (!pm.p) return DTP_ERR_HIP;
+    GemmParams g = {};
+    g.A = y2.p; g.W = up.xW1[i]; g.C = pm.p;
+    g.M = S; g.N = 128; g.K = C; g.lda = y2.ld; g.ldw = C; g.ldc = pm.ld; g.nkb = C / 64;
+    g.bias = up.xb1[i]; g.lns = up.xl1[i]; g.ln_eps = 1e-5f;
+    g.flags = GF_BIAS | GF_LNFOLD | GF_SOFTMAX16; g.sm_valid = 14;
+    g.batch = N; g.a_bs = (long long)S * y2.ld; g.w_bs = (long long)128 * C; g.c_bs = (long long)S * pm.ld; g.bias_bs = 128; g.lns_bs = 128;
+    if (st2.buf && st2.parts > 0 && st2.M == N * S) { g.st_in = st2.buf; g.st_parts = st2.parts; g.st_rows = N * S; }
+    RC(push_gemm(b.c, b.prog, g, -1, (double)C, nullptr));
+    b.release_stats(st2);
+    RC(b.alloc_stats(x.rows(), C, st3));
+    y3 = b.alloc(x.B, x.H, x.W, C);
+    if (!y3.p) return DTP_ERR_HIP;
+    GemmParams h = {};
+    h.A = pm.p; h.W = up.xW2[i]; h.C = y3.p;
+    h.M = S; h.N = C; h.K = 128; h.lda = pm.ld; h.ldw = 128; h.ldc = y3.ld; h.nkb = 2;
+    h.bias = w.out2.b; h.R = y2.p; h.ldr = y2.ld;
+    h.flags = (w.out2.b ? GF_BIAS : 0) | GF_RESID | (st3.buf ? GF_ROWSTATS : 0);
+    h.st_out = st3.buf; h.st_rows = N * S;
+    h.batch = N; h.a_bs = (long long)S * pm.ld; h.w_bs = (long long)Cp * 128; h.c_bs = (long long)S * y3.ld; h.r_bs = (long long)S * y2.ld;
+    RC(push_gemm(b.c, b.prog, h, -1, 128.0, st3.buf ? &st3 : nullptr));
+    b.release(pm); b.release(y2);
+  }
   RC(b.linear(y3, w.ff1, nullptr, GF_GEGLU, f, nullptr, &st3));  // LN3 folded
   b.release_stats(st3);
   RC(b.linear(f, w.ff2, &y3, 0, y4));
@@ -209,20 +234,50 @@ int build_unet_prog(Ctx* c, int N, UNetProg& up) {
   xfs.push_back(&u.mid_xf);
   for (int i = 1; i < 4; ++i) for (int j = 0; j < 3; ++j) xfs.push_back(&u.up_xf[i][j]);
   up.kvbuf.assign(xfs.size(), nullptr);
+  up.xW1.assign(xfs.size(), nullptr); up.xW2.assign(xfs.size(), nullptr);
+  up.xb1.assign(xfs.size(), nullptr); up.xl1.assign(xfs.size(), nullptr);
+  RC(ctx_persistent(c, (size_t)N * 128 * 1280 * 2, &p, true)); up.kexp = (f16*)p;
+  RC(ctx_persistent(c, (size_t)N * 128 * 1280 * 2, &p, true)); up.vexp = (f16*)p;
   {
     Builder b{c, &up.kv};
     T ctx;
     ctx.p = up.ctx16; ctx.B = N; ctx.H = 1; ctx.W = 14; ctx.C = 768; ctx.ld = 768;
+    auto plain = [&](GemmParams g, int tile) {
+      g.zero = c->zero; g.splits = 1; g.kb_per_split = g.nkb;
+      const double nb = g.batch > 1 ? g.batch : 1;
+      b.push(PK_GEMM0 + tile, 2.0 * nb * g.M * (double)g.N * g.K, 2.0 * nb * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N),
+             [=](hipStream_t s, int) { return dtp_launch_gemm(g, tile, s); });
+    };
     for (const XfW* w : xfs) {
-      RC(ctx_persistent(c, (size_t)N * 14 * w->kv2.cout * 2, &p, true));
-      up.kvbuf[w->kv_index] = (f16*)p;
-      GemmParams g = {};
-      g.A = ctx.p; g.W = w->kv2.w; g.C = p;
-      g.M = N * 14; g.N = w->kv2.cout; g.K = 768; g.lda = 768; g.ldw = w->kv2.ldw; g.ldc = w->kv2.cout; g.nkb = w->kv2.ldw / 64;
-      g.zero = c->zero;
-      g.splits = 1; g.kb_per_split = g.nkb;
-      b.push(PK_GEMM0 + 3, 2.0 * g.M * (double)g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N),
-             [=](hipStream_t s, int) { return dtp_launch_gemm(g, 3, s); });
+      const int C = w->q2.K, Cp = (C + 127) / 128 * 128, i = w->kv_index;
+      if (w->kv2.cout != 2 * C || w->out2.K != C || (C % 64) || !w->q2.b || !w->q2T) { dtp_set_error("cross-attention: unexpected weight shapes"); return DTP_ERR_ARG; }
+      RC(ctx_persistent(c, (size_t)N * 14 * 2 * C * 2, &p, true)); up.kvbuf[i] = (f16*)p;
+      RC(ctx_persistent(c, (size_t)N * 128 * C * 2, &p, true)); up.xW1[i] = (f16*)p;
+      RC(ctx_persistent(c, (size_t)N * Cp * 128 * 2, &p, true)); up.xW2[i] = (f16*)p;
+      RC(ctx_persistent(c, (size_t)N * 128 * 4, &p, true)); up.xb1[i] = (float*)p;
+      RC(ctx_persistent(c, (size_t)N * 128 * 4, &p, true)); up.xl1[i] = (float*)p;
+      GemmParams g = {};  // K | V of the 14 context tokens
+      g.A = ctx.p; g.W = w->kv2.w; g.C = up.kvbuf[i];
+      g.M = N * 14; g.N = 2 * C; g.K = 768; g.lda = 768; g.ldw = w->kv2.ldw; g.ldc = 2 * C; g.nkb = w->kv2.ldw / 64;
+      plain(g, 3);
+      f16 *kvb = up.kvbuf[i], *kexp = up.kexp, *vexp = up.vexp, *W1 = up.xW1[i];
+      float *b1 = up.xb1[i], *l1 = up.xl1[i];
+      const float* bq = w->q2.b;
+      const float scale = 1.0f / sqrtf((float)(C / 8));
+      b.push(PK_ELEM, 0.0, 0.0, [=](hipStream_t s, int) { return dtp_launch_expand_kv(kvb, kexp, vexp, N, 14, C, 8, scale, s); });
+      GemmParams g1 = {};  // score matrix: rows (n, h, j), K = to_q output channel
+      g1.A = kexp; g1.W = w->q2T; g1.C = W1;
+      g1.M = N * 128; g1.N = C; g1.K = C; g1.lda = C; g1.ldw = C; g1.ldc = C; g1.nkb = C / 64;
+      plain(g1, 3);
+      b.push(PK_ELEM, 0.0, 0.0, [=](hipStream_t s, int) {
+        RC(dtp_launch_rowsum_f16(W1, C, C, l1, N * 128, s));
+        return dtp_launch_rowdot_f16(kexp, C, bq, b1, N * 128, C, s);
+      });
+      GemmParams g2 = {};  // value-output matrix per sample: [C][128] = Wo . Vexp_n^T, stored as packed weights of the 2nd GEMM
+      g2.A = w->out2.w; g2.W = vexp; g2.C = up.xW2[i];
+      g2.M = C; g2.N = 128; g2.K = C; g2.lda = w->out2.ldw; g2.ldw = C; g2.ldc = 128; g2.nkb = C / 64;
+      g2.batch = N; g2.a_bs = 0; g2.w_bs = (long long)128 * C; g2.c_bs = (long long)Cp * 128;
+      plain(g2, 3);
     }
   }
   // ---- main program

@@ -59,14 +59,16 @@ def rowsum(wp, k):
     return out
 
 
-def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, out=None, lda=None, lns=None, ln_eps=1e-5):
-    """a f16 [M, >=K] row-major; wp packed weights; returns f16 [M, N] (or [M, N/2] with GEGLU)."""
+def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, out=None, lda=None, lns=None, ln_eps=1e-5, batch=0,
+         sm_valid=0, bias_shared=False):
+    """a f16 [M, >=K] row-major; wp packed weights; returns f16 [M, N] (or [M, N/2] with GEGLU).
+    batch > 1: a is [batch*M, K] (problem b = rows b*M..), wp is [batch*Npad, Kpad], bias / lns are [batch*Npad]."""
     lib = _lib.load()
-    m = a.shape[0]
+    m = a.shape[0] // batch if batch > 1 else a.shape[0]
     k = k or a.shape[1]
     n_out = n // 2 if flags & GF_GEGLU else n
     if out is None:
-        out = torch.empty(m, n_out, dtype=torch.float32 if flags & GF_OUT_F32 else torch.float16, device=a.device)
+        out = torch.empty(a.shape[0], n_out, dtype=torch.float32 if flags & GF_OUT_F32 else torch.float16, device=a.device)
     d = GemmDesc()
     d.A, d.W, d.C = a.data_ptr(), wp.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -79,6 +81,11 @@ def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, ou
     if lns is not None:
         d.lns, d.ln_eps = lns.data_ptr(), ln_eps
         d.flags |= GF_LNFOLD
+    if batch > 1:
+        npad = wp.shape[0] // batch
+        d.batch, d.a_bs, d.w_bs, d.c_bs = batch, m * d.lda, npad * d.ldw, m * d.ldc
+        d.r_bs, d.bias_bs, d.lns_bs = m * d.ldr, 0 if bias_shared else npad, npad
+    d.sm_valid = sm_valid
     check(lib.dtp_op_gemm(C.byref(d), _stream()), "gemm")
     return out
 

@@ -141,9 +141,14 @@ typedef struct {
   const void* A2;    /* conv only: fused 1x1-shortcut tail, f16 [M][lda2] with Cin2 channels appended to K (W = [W3x3 | W1x1]) */
   int lda2, Cin2;
   const void* Wcb;   /* 3x3 conv: channel-block-major packing (dtp_op_pack_conv_cb); selects conv_halo_kernel when tile = 12..15 */
+  int batch;         /* grouped dense problems (0/1 = one): problem b reads A + b*a_bs, W + b*w_bs, R + b*r_bs, bias + b*bias_bs,
+                        lns + b*lns_bs and writes C + b*c_bs (strides in elements) */
+  int64_t a_bs, w_bs, c_bs, r_bs;
+  int bias_bs, lns_bs;
+  int sm_valid;      /* DTP_GF_SOFTMAX16: softmax over the first sm_valid columns of every aligned group of 16; the rest -> 0 */
 } dtp_gemm_desc;
 enum { DTP_GF_BIAS = 1, DTP_GF_BIAS_M = 2, DTP_GF_RESID = 4, DTP_GF_GEGLU = 8, DTP_GF_GELU = 64, DTP_GF_QUICKGELU = 128,
-       DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512, DTP_GF_LNFOLD = 1024 };
+       DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512, DTP_GF_LNFOLD = 1024, DTP_GF_SOFTMAX16 = 4096 };
 
 int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s);
 /* w f32 [N][K] -> out f16 [rows][ldw] (caller zero-fills out); geglu=1 applies the [a|gate] tile packing */

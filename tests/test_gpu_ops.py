@@ -117,6 +117,42 @@ def test_gemm_layernorm_fold(ops, m, c, n, tile, geglu):
     close(got, ref, tol=3e-3)
 
 
+@pytest.mark.parametrize("tile", [-1, 2, 5, 8])
+def test_gemm_batched_group_softmax(ops, tile):
+    """Grouped GEMM (one weight matrix per batch entry) + LayerNorm fold + softmax over groups of 16 columns (14 valid):
+    the first half of the algebraically fused cross-attention (scores against 14 context tokens, 8 heads)."""
+    from diffusiontexturepainting_amd._lib import GF_BIAS, GF_SOFTMAX16
+    nb, m, c = 3, 200, 320
+    x = rnd(nb * m, c, seed=70) * 1.3 + 0.2
+    w = rnd(nb, 128, c, seed=71, scale=2.0 * c ** -0.5).float()
+    g = torch.Generator().manual_seed(72)
+    gamma, beta, bias = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g), 0.3 * torch.randn(nb, 128, generator=g)
+    xn = F.layer_norm(x.float(), (c,), gamma, beta, 1e-5).view(nb, m, c)
+    sc = torch.einsum("bmc,bnc->bmn", xn, w) + bias[:, None]
+    sc = sc.view(nb, m, 8, 16)
+    ref = torch.zeros_like(sc)
+    ref[..., :14] = torch.softmax(sc[..., :14], dim=-1)
+    wp = torch.cat([ops.pack_linear((w[b] * gamma[None]).cuda()) for b in range(nb)], dim=0).contiguous()
+    b2 = (bias + torch.einsum("bnc,c->bn", w, beta)).reshape(-1)
+    lns = ops.rowsum(wp, c)
+    got = ops.gemm(x.cuda(), wp, 128, c, bias=b2.cuda(), lns=lns, tile=tile, flags=GF_BIAS | GF_SOFTMAX16, batch=nb, sm_valid=14)
+    close(got, ref.view(nb * m, 128), tol=3e-3)
+
+
+def test_gemm_batched_residual(ops):
+    """Second half: P [b*M, 128] times a per-entry [N, 128] matrix, + bias + residual."""
+    nb, m, n = 3, 130, 320
+    pm = torch.rand(nb * m, 128, generator=torch.Generator().manual_seed(73)).half()
+    w = rnd(nb, n, 128, seed=74, scale=0.1).float()
+    bias = torch.randn(n, generator=torch.Generator().manual_seed(75))
+    r = rnd(nb * m, n, seed=76)
+    ref = torch.einsum("bmk,bnk->bmn", pm.float().view(nb, m, 128), w).reshape(nb * m, n) + bias + r.float()
+    wp = torch.cat([ops.pack_linear(w[b].cuda()) for b in range(nb)], dim=0).contiguous()
+    from diffusiontexturepainting_amd._lib import GemmDesc
+    got = ops.gemm(pm.cuda(), wp, n, 128, bias=bias.cuda().repeat(1), resid=r.cuda(), batch=nb, bias_shared=True)
+    close(got, ref)
+
+
 def test_gemm_epilogues(ops):
     from diffusiontexturepainting_amd._lib import GF_BIAS_M, GF_GELU, GF_QUICKGELU
     m, n, k = 130, 256, 192
