@@ -51,6 +51,17 @@ def cpu_baseline(res, ddim_steps, weights, budget_note):
                       f"extrapolated to {ddim_steps - 1} evals + 2 encodes + 1 decode = {stamp_s:.1f}s/stamp; {budget_note}"}
 
 
+def pmc_traffic(batch):
+    """HBM bytes per launch of the implicit-GEMM kernel class from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
+    (profiles/, collected by tools/pmc_unet.sh on eager UNet evaluations: counters cannot be read from inside this process)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_unet_traffic.json")
+    if batch != 1 or not os.path.exists(path):
+        return {"traffic": None}
+    t = json.load(open(path))
+    return {"traffic": t["traffic_bytes_per_launch"], "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
+            "traffic_source": "profiles/r01_pmc_unet_traffic.json"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,7 +134,9 @@ def main():
             "achieved": g_fl / (g_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": g_fl / (g_ms * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS,
             "launches": g_n, "avg_launch_us": g_ms * 1e3 / g_n, "share_of_gpu_time": g_ms / tot_ms,
-            "algorithmic_tflop_per_step": g_fl / 1e12, "traffic": None,
+            "algorithmic_tflop_per_step": g_fl / 1e12,
+            "algorithmic_bytes_per_launch": sum(r["bytes"] for r in gem) / g_n,
+            **pmc_traffic(a.batch),
             "dominant_instantiation": {"kernel": dom["kernel"], "launches": dom["launches"],
                                        "avg_launch_us": dom["ms"] * 1e3 / dom["launches"],
                                        "achieved": dom["flops"] / (dom["ms"] * 1e-3) / 1e12,
