@@ -91,6 +91,8 @@ def load():
                        "(there is no CPU or PyTorch fallback for the stamp path)")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
+        if os.environ.get("DTP_LIB") and not hasattr(lib, name):
+            continue  # A/B against an older build of the ABI: entry points it lacks simply stay unbound
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
