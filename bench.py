@@ -78,9 +78,13 @@ def main():
     from diffusiontexturepainting_amd import dist as D, synthetic, weights as W
     from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
 
-    rank, world, local = D.init_from_env("nccl")
+    # DTP_BENCH_BACKEND=gloo + DTP_BENCH_SAME_DEVICE=1: every rank on GPU 0 -- exercises the N>1 control flow (rendezvous, shared
+    # tune cache, barriers, max-over-ranks timing, gather) on a 1-GPU box; the real runs use RCCL, one GPU per rank
+    rank, world, local = D.init_from_env(os.environ.get("DTP_BENCH_BACKEND", "nccl"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if os.environ.get("DTP_BENCH_SAME_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

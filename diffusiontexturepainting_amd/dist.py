@@ -49,11 +49,14 @@ def gather_patches(local, n_total, rank, world, dst=0):
         pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
     local = local.contiguous()
+    dev = local.device
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        local = local.cpu()  # gloo has no CUDA gather: stage through host memory (CPU tests and the single-GPU 2-rank smoke run)
     bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
     dist.gather(local, gather_list=bufs, dst=dst)
     if rank != dst:
         return None
-    return torch.cat([b[:n] for b, n in zip(bufs, counts)], dim=0)
+    return torch.cat([b[:n] for b, n in zip(bufs, counts)], dim=0).to(dev)
 
 
 def barrier():
