@@ -398,8 +398,7 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
       }
     }
     // halo-tiled 3x3 variants (tile ids 12..15); their split-K runs over 64-channel blocks
-    static const bool no_halo_tail = getenv("DTP_NO_HALO_TAIL") != nullptr;  // A/B switch for measurements
-    if (p.Wcb && dtp_conv_halo_supported(p) && !(no_halo_tail && p.A2)) {
+    if (p.Wcb && dtp_conv_halo_supported(p)) {
       for (int v = 0; v < 4; ++v) {
         if ((v >= 2) != (p.Hi * p.Wi <= 256)) continue;  // 8x8 pixel tiles for small feature maps, 8x16 otherwise
         for (int sp : cand_splits) {
