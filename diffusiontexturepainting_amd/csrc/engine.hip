@@ -349,7 +349,8 @@ void tune_cache_save(Ctx* c) {
 // with every tile variant x split-K factor on the real buffers and the fastest pair is kept.
 static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   char key[200];
-  int kl = snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
+  // "k3|": bump when tile ids or pipelines change, so that a persisted table written by an older build is ignored
+  int kl = snprintf(key, sizeof(key), "k3|%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
                     p.stride, p.lda, p.ldc, p.ldw, p.st_parts, p.Cin2, p.lda2);
   if (p.batch > 1) snprintf(key + kl, sizeof(key) - kl, ",b%d", p.batch);
   auto it = c->tuned.find(key);
