@@ -96,8 +96,9 @@ struct GemmParams {
   int splits;        // grid.z
   int kb_per_split;
   int Hi, Wi, Ho, Wo, Cin, stride, pad;  // CONV3 geometry (Hi/Wi are the stored input dims)
-  const f16* A2;     // CONV3 only: a 10th, dense "tap" appended to K -- the ResBlock's 1x1 shortcut conv, read from the
-  int lda2, Cin2;    // block input [M][lda2] (Cin2 channels, multiple of 64); null / 0 = none
+  const f16* A2;     // CONV3: a 10th, dense "tap" appended to K -- the ResBlock's 1x1 shortcut conv, read from the block input
+  int lda2, Cin2;    // [M][lda2] (Cin2 channels, multiple of 64); dense GEMM: a second activation matrix supplying the LAST Cin2
+                     // columns of the contraction (K - Cin2 from A, then Cin2 from A2; both multiples of 64); null / 0 = none
   int flags;
   // batched (grouped) problems: grid.y = batch; problem b uses A + b*a_bs, W + b*w_bs, C + b*c_bs, R + b*r_bs (elements),
   // bias + b*bias_bs, lns + b*lns_bs.  Row statistics stay indexed by the global row b*M + m of a [parts][st_rows][2] array.
@@ -145,6 +146,7 @@ int dtp_launch_pack_linear_weight(const float* w, f16* out, int N, int K, int ld
 int dtp_launch_rowdot(const float* w, const float* v, float* out, int N, int K, hipStream_t s);
 int dtp_launch_scale_cols(float* w, const float* g, int N, int K, hipStream_t s);
 int dtp_launch_rowsum_f16(const f16* w, int ld, int K, float* out, int rows, hipStream_t s);
+int dtp_launch_matmul_f32(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s);
 int dtp_launch_expand_kv(const f16* kv, f16* kexp, f16* vexp, int N, int T, int C, int H, float scale, hipStream_t s);
 int dtp_launch_transpose_f16(const f16* src, int lds_, f16* dst, int ldd, int rows, int cols, hipStream_t s);
 int dtp_launch_rowdot_f16(const f16* a, int ld, const float* v, float* out, int rows, int K, hipStream_t s);

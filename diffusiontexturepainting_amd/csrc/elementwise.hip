@@ -180,6 +180,25 @@ __global__ __launch_bounds__(256) void rowdot_f16_kernel(const f16* __restrict__
   if (lane == 0) out[r] = s;
 }
 
+
+// C[M][N] = A[M][K] . B[K][N], all fp32 row-major: weight-load-time products only (e.g. proj_out . ff2), 16x16 LDS tiles
+__global__ __launch_bounds__(256) void matmul_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
+                                                         int N, int K) {
+  __shared__ float as[16][17], bs[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    as[ty][tx] = (m < M && k0 + tx < K) ? A[(size_t)m * K + k0 + tx] : 0.f;
+    bs[ty][tx] = (k0 + ty < K && n < N) ? B[(size_t)(k0 + ty) * N + n] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) acc += as[ty][kk] * bs[kk][tx];
+    __syncthreads();
+  }
+  if (m < M && n < N) C[(size_t)m * N + n] = acc;
+}
+
 }  // namespace
 
 #define LAUNCH_RET() return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP
@@ -234,6 +253,10 @@ int dtp_launch_transpose_f16(const f16* src, int lds_, f16* dst, int ldd, int ro
 }
 int dtp_launch_rowdot_f16(const f16* a, int ld, const float* v, float* out, int rows, int K, hipStream_t s) {
   hipLaunchKernelGGL(rowdot_f16_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, a, ld, v, out, rows, K);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
+int dtp_launch_matmul_f32(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(matmul_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, s, A, B, C, M, N, K);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 int dtp_launch_rowdot(const float* w, const float* v, float* out, int N, int K, hipStream_t s) {

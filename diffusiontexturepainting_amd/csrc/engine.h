@@ -70,7 +70,8 @@ struct ResW {
 };
 struct XfW {
   NormW gn, ln1, ln2, ln3;
-  ConvW proj_in, qkv, out1, q2, kv2, out2, ff1, ff2, proj_out;
+  ConvW proj_in, qkv, out1, q2, kv2, out2, ff1;
+  ConvW ff2_proj;  // ff.net.2 and proj_out merged (load_linear_pair): [f | y3] -> block output in one GEMM
   int kv_index = -1;  // which cross-attention K/V buffer
   f16* q2T = nullptr; // LayerNorm-folded to_q of the cross-attention, transposed and packed: [up(C,128)][C] (rows = input channel)
 };
@@ -231,6 +232,9 @@ int load_norm(Ctx* c, const std::string& name, NormW& n);
 int load_conv(Ctx* c, const std::string& name, ConvW& w, int cin_pad = 0, bool bias = true);
 // ResBlock tail: conv2 (3x3) and the 1x1 shortcut conv packed as ONE contraction [W2 | Wsc], bias = b2 + bsc
 int load_conv_with_shortcut(Ctx* c, const std::string& conv, const std::string& shortcut, ConvW& w);
+// two Linears in a row with only a residual between them, out = Wb (Wa f + ba + r) + bb, merged into ONE contraction over
+// [f | r]: W = [Wb Wa | Wb] (product in fp32 at load time), bias = Wb ba + bb.  K = Ka + Kb.
+int load_linear_pair(Ctx* c, const std::string& first, const std::string& second, ConvW& w);
 // stacked linear: rows of several [n_i][K] matrices one after another; geglu packs the [a|gate] tile order
 int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bias, bool geglu = false,
                 const std::string& fold_ln = std::string());  // fold_ln: name of the LayerNorm feeding this Linear

@@ -157,6 +157,38 @@ int load_conv_with_shortcut(Ctx* c, const std::string& conv, const std::string& 
   return ctx_upload_f32(c, b1, &w.b);
 }
 
+int load_linear_pair(Ctx* c, const std::string& first, const std::string& second, ConvW& w) {
+  const Staged *wa = ctx_find(c, first + ".weight"), *wb = ctx_find(c, second + ".weight");
+  const Staged *ba = ctx_find(c, first + ".bias"), *bb = ctx_find(c, second + ".bias");
+  if (!wa || !wb || !ba || !bb) { dtp_set_error("linear pair: missing '%s' / '%s'", first.c_str(), second.c_str()); return DTP_ERR_MISSING; }
+  const int Na = (int)wa->shape[0], Ka = (int)(wa->n / Na), Nb = (int)wb->shape[0], Kb = (int)(wb->n / Nb);  // wb may be a 1x1 conv
+  if (Kb != Na || (Ka & 63) || (Kb & 63)) { dtp_set_error("linear pair: shapes [%d,%d] then [%d,%d] do not chain", Na, Ka, Nb, Kb); return DTP_ERR_ARG; }
+  const int K = Ka + Kb;
+  float *prod = nullptr, *cat = nullptr, *bias = nullptr;
+  HIP_CHECK(hipMalloc(&prod, (size_t)Nb * Ka * 4));
+  HIP_CHECK(hipMalloc(&cat, (size_t)Nb * K * 4));
+  HIP_CHECK(hipMalloc(&bias, (size_t)Nb * 4));
+  RC(dtp_launch_matmul_f32(wb->d, wa->d, prod, Nb, Ka, Kb, 0));  // Wb . Wa  [Nb][Ka]
+  HIP_CHECK(hipMemcpy2DAsync(cat, (size_t)K * 4, prod, (size_t)Ka * 4, (size_t)Ka * 4, Nb, hipMemcpyDeviceToDevice, 0));
+  HIP_CHECK(hipMemcpy2DAsync(cat + Ka, (size_t)K * 4, wb->d, (size_t)Kb * 4, (size_t)Kb * 4, Nb, hipMemcpyDeviceToDevice, 0));
+  RC(dtp_launch_rowdot(wb->d, ba->d, bias, Nb, Kb, 0));  // Wb . ba
+  w = ConvW();
+  w.cout = Nb; w.cin = K; w.cin_true = K; w.taps = 1; w.K = K; w.ldw = (int)up_to(K, 64);
+  void* p;
+  RC(ctx_arena_alloc(c, up_to(Nb, 128) * (size_t)w.ldw * 2, &p));
+  w.w = (f16*)p;
+  RC(dtp_launch_pack_linear_weight(cat, w.w, Nb, K, w.ldw, nullptr, 0));
+  std::vector<float> hb(Nb), hb2;
+  HIP_CHECK(hipMemcpy(hb.data(), bias, (size_t)Nb * 4, hipMemcpyDeviceToHost));
+  RC(ctx_fetch_host(c, second + ".bias", hb2));
+  for (int i = 0; i < Nb; ++i) hb[i] += hb2[i];
+  hb.resize(up_to(hb.size(), 128), 0.f);
+  RC(ctx_upload_f32(c, hb, &w.b));
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipFree(prod)); HIP_CHECK(hipFree(cat)); HIP_CHECK(hipFree(bias));
+  return DTP_OK;
+}
+
 int load_linear(Ctx* c, const std::vector<std::string>& names, ConvW& w, bool bias, bool geglu, const std::string& fold_ln) {
   int N = 0, K = -1;
   for (const auto& nm : names) {

@@ -126,6 +126,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
   // 1 KiB).  A piece costs the issuing wave 60-180 cycles, so the main loop spreads them between its MFMAs instead of
   // issuing them back to back in front of the MFMAs.
   size_t a_off = 0, w_off = 0;
+  bool dense_tail = false;
+  const int dense_k1 = p.K - p.Cin2;  // dense two-operand GEMM: first column read from A2
   auto prep = [&](int kb) {
     if (conv) {
       // The tap (ky,kx) only changes every Cin/64 k-blocks: the per-row bounds test and pixel address are
@@ -153,7 +155,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
       if (tap < 9) { while (cch >= p.Cin) { cch -= p.Cin; ++tap; } }
       else if (cch >= p.Cin2) { cch -= p.Cin2; ++tap; }
     } else {
-      a_off = (size_t)kb * 64;
+      // dense GEMM with a second activation matrix: columns [K - Cin2, K) of the contraction come from A2 (same rows)
+      if (p.A2 && !dense_tail && kb * 64 >= dense_k1) {
+        dense_tail = true;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+          const int m = m0 + i * 32 + lrow;
+          a_row[i] = (m < p.M) ? p.A2 + (size_t)m * p.lda2 + kc : nullptr;
+        }
+      }
+      a_off = (size_t)(kb * 64 - (dense_tail ? dense_k1 : 0));
     }
     w_off = (size_t)kb * 64;
   };
@@ -611,8 +622,13 @@ int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
   if (p.nkb <= 0 || p.M <= 0 || p.N <= 0) { dtp_set_error("gemm: empty problem"); return DTP_ERR_ARG; }
   if ((p.lda & 7) || (p.ldw & 7)) { dtp_set_error("gemm: lda/ldw must be multiples of 8"); return DTP_ERR_ARG; }
   if ((p.flags & GF_CONV3) && (p.Cin & 7)) { dtp_set_error("conv: Cin must be a multiple of 8"); return DTP_ERR_ARG; }
-  if (p.A2 && (!(p.flags & GF_CONV3) || ((9 * p.Cin) & 63) || (p.Cin2 & 63) || (p.lda2 & 7) || p.stride != 1)) {
+  if (p.A2 && (p.flags & GF_CONV3) && (((9 * p.Cin) & 63) || (p.Cin2 & 63) || (p.lda2 & 7) || p.stride != 1)) {
     dtp_set_error("conv: fused shortcut tail needs stride 1 and 9*Cin, Cin2 multiples of 64");
+    return DTP_ERR_ARG;
+  }
+  if (p.A2 && !(p.flags & GF_CONV3) && ((p.Cin2 & 63) || ((p.K - p.Cin2) & 63) || p.Cin2 <= 0 || p.Cin2 >= p.K || (p.lda2 & 7) ||
+                                       (p.flags & GF_LNFOLD))) {
+    dtp_set_error("gemm: a second activation matrix needs K - Cin2 and Cin2 to be multiples of 64 and no LayerNorm fold");
     return DTP_ERR_ARG;
   }
   if (p.batch > 1 && (p.splits > 1 || (p.flags & GF_CONV3))) { dtp_set_error("gemm: batched problems are dense and unsplit"); return DTP_ERR_ARG; }

@@ -37,8 +37,7 @@ static int load_xf(Ctx* c, const std::string& p, XfW& w, int& kv_counter) {
   RC(load_linear(c, {t + ".attn2.to_k", t + ".attn2.to_v"}, w.kv2, false));
   RC(load_linear(c, {t + ".attn2.to_out.0"}, w.out2, true));
   RC(load_linear(c, {t + ".ff.net.0.proj"}, w.ff1, true, true, t + ".norm3"));
-  RC(load_linear(c, {t + ".ff.net.2"}, w.ff2, true));
-  RC(load_conv(c, p + ".proj_out", w.proj_out));
+  RC(load_linear_pair(c, t + ".ff.net.2", p + ".proj_out", w.ff2_proj));
   w.kv_index = kv_counter++;
   {  // transposed copy of the folded to_q for the per-stamp score-matrix GEMM (rows = input channel, K = output channel)
     const int C = w.q2.K, rows = (C + 127) / 128 * 128, ld = (C + 63) / 64 * 64;
@@ -165,7 +164,7 @@ int ensure_temb(Ctx* c, const std::vector<float>& timesteps) {
 
 static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up, T& out, const T* dst = nullptr) {
   const int C = x.C, S = x.H * x.W, N = x.B;
-  T t, y, n1, qkv, a, y2, n2, y3, n3, f, y4;
+  T t, y, n1, qkv, a, y2, n2, y3, n3, f;
   RC(b.gn(x, w.gn, 1e-6f, false, t));
   // LayerNorms are folded into their consumer GEMMs; the row statistics ride on the producer's epilogue
   RowStats st1, st2, st3;
@@ -213,10 +212,28 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
   }
   RC(b.linear(y3, w.ff1, nullptr, GF_GEGLU, f, nullptr, &st3));  // LN3 folded
   b.release_stats(st3);
-  RC(b.linear(f, w.ff2, &y3, 0, y4));
-  b.release(f); b.release(y3);
-  RC(b.linear(y4, w.proj_out, &x, 0, out, nullptr, nullptr, dst));
-  b.release(y4);
+  // ff.net.2 (+ y3) and proj_out (+ x) are two Linears with only a residual add between them: one GEMM over [f | y3]
+  // with the merged weights [Wp W2 | Wp] (load_linear_pair) -- no y4 tensor, one launch fewer per block
+  {
+    const ConvW& wm = w.ff2_proj;
+    if (wm.K != f.C + y3.C || wm.cout != C) { dtp_set_error("transformer: merged ff2/proj_out weight mismatch"); return DTP_ERR_ARG; }
+    if (dst) {
+      if (dst->C != C || dst->rows() != x.rows()) { dtp_set_error("transformer: destination view mismatch"); return DTP_ERR_ARG; }
+      out = *dst;
+    } else {
+      out = b.alloc(x.B, x.H, x.W, C);
+      if (!out.p) return DTP_ERR_HIP;
+    }
+    GemmParams g = {};
+    g.A = f.p; g.lda = f.ld; g.A2 = y3.p; g.lda2 = y3.ld; g.Cin2 = y3.C;
+    g.W = wm.w; g.ldw = wm.ldw; g.nkb = wm.ldw / 64;
+    g.M = (int)x.rows(); g.N = C; g.K = wm.K;
+    g.C = out.p; g.ldc = out.ld;
+    g.bias = wm.b; g.R = x.p; g.ldr = x.ld;
+    g.flags = GF_BIAS | GF_RESID;
+    RC(push_gemm(b.c, b.prog, g, -1, (double)wm.K, nullptr));
+    b.release(f); b.release(y3);
+  }
   return DTP_OK;
 }
 

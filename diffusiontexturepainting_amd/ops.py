@@ -60,7 +60,7 @@ def rowsum(wp, k):
 
 
 def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, out=None, lda=None, lns=None, ln_eps=1e-5, batch=0,
-         sm_valid=0, bias_shared=False):
+         sm_valid=0, bias_shared=False, tail=None):
     """a f16 [M, >=K] row-major; wp packed weights; returns f16 [M, N] (or [M, N/2] with GEGLU).
     batch > 1: a is [batch*M, K] (problem b = rows b*M..), wp is [batch*Npad, Kpad], bias / lns are [batch*Npad]."""
     lib = _lib.load()
@@ -86,6 +86,9 @@ def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, ou
         d.batch, d.a_bs, d.w_bs, d.c_bs = batch, m * d.lda, npad * d.ldw, m * d.ldc
         d.r_bs, d.bias_bs, d.lns_bs = m * d.ldr, 0 if bias_shared else npad, npad
     d.sm_valid = sm_valid
+    if tail is not None:  # second activation matrix: supplies the last tail.shape[1] columns of the contraction
+        d.A2, d.lda2, d.Cin2 = tail.data_ptr(), tail.stride(0), tail.shape[1]
+        d.K = k + tail.shape[1]
     check(lib.dtp_op_gemm(C.byref(d), _stream()), "gemm")
     return out
 

@@ -153,6 +153,18 @@ def test_gemm_batched_residual(ops):
     close(got, ref)
 
 
+@pytest.mark.parametrize("m,k1,k2,n,tile,splits", [(300, 1280, 320, 320, -1, 0), (130, 256, 64, 192, 2, 3), (768, 640, 128, 640, 17, 1), (64, 128, 128, 128, 5, 2)])
+def test_gemm_two_activation_matrices(ops, m, k1, k2, n, tile, splits):
+    """[f | r] . [W1 | W2]^T with f and r in separate buffers: how ff.net.2 (+residual) and proj_out run as one GEMM."""
+    f, r = rnd(m, k1, seed=30), rnd(m, k2, seed=31)
+    w = rnd(n, k1 + k2, seed=32, scale=(k1 + k2) ** -0.5)
+    bias = torch.randn(n, generator=torch.Generator().manual_seed(33))
+    res = rnd(m, n, seed=34)
+    ref = F.linear(torch.cat([f, r], dim=1).float(), w.float(), bias) + res.float()
+    got = ops.gemm(f.cuda(), ops.pack_linear(w.float().cuda()), n, k1, bias=bias.cuda(), resid=res.cuda(), tail=r.cuda(), tile=tile, splits=splits)
+    close(got, ref)
+
+
 def test_gemm_epilogues(ops):
     from diffusiontexturepainting_amd._lib import GF_BIAS_M, GF_GELU, GF_QUICKGELU
     m, n, k = 130, 256, 192
