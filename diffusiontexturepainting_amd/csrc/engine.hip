@@ -395,6 +395,41 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     int bt = *tile_out, bs = p.splits;
     const bool geglu = (p.flags & GF_GEGLU) != 0;
     static const int cand_splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+    // One candidate = (tile id, split-K factor); tile ids 12..15 are the halo-tiled conv kernels (they read the Wcb packing).
+    // Timed the way the stamp sees it: weights COLD (1.7 GB of them stream through the 256 MiB Infinity Cache every UNet
+    // evaluation), activations warm (just written by the previous kernel); minimum over `reps` runs (a single cold run is noisy:
+    // DVFS, thrash write-back still draining).  Returns < 0 when the candidate does not apply.
+    auto time_cfg = [&](int tile, int sp, int reps, float* out_ms) -> int {
+      *out_ms = -1.f;
+      GemmParams q = p;
+      const bool halo = tile >= 12 && tile < 16;
+      if (halo) q.W = p.Wcb;
+      q.kb_per_split = (p.nkb + sp - 1) / sp;
+      q.splits = (p.nkb + q.kb_per_split - 1) / q.kb_per_split;
+      if (q.splits != sp && sp > 1) return DTP_OK;
+      const size_t need = dtp_gemm_workspace_bytes(q);
+      if (need > ((size_t)512 << 20)) return DTP_OK;
+      if (need > c->ws_bytes) { c->ws_need = std::max(c->ws_need, need); RC(ensure_ws(c)); }
+      q.part = c->ws;
+      q.zero = c->zero;
+      float ms = 1e30f;
+      for (int rep = 0; rep < reps; ++rep) {
+        HIP_CHECK(hipMemsetAsync(c->tune_thrash, rep, THRASH_BYTES, 0));
+        RC(dtp_launch_touch(q.A, a_bytes, (float*)c->tune_thrash, 0));
+        if (q.R) RC(dtp_launch_touch(q.R, (size_t)q.M * q.ldr * 2, (float*)c->tune_thrash, 0));
+        HIP_CHECK(hipEventRecord(c->tune_ev[0], 0));
+        if (halo) RC(dtp_launch_conv_halo(q, tile - 12, 0)); else RC(dtp_launch_gemm(q, tile, 0));
+        HIP_CHECK(hipEventRecord(c->tune_ev[1], 0));
+        HIP_CHECK(hipEventSynchronize(c->tune_ev[1]));
+        float t = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&t, c->tune_ev[0], c->tune_ev[1]));
+        ms = std::min(ms, t);
+      }
+      *out_ms = ms;
+      return DTP_OK;
+    };
+    struct Cand { float ms; int tile, sp; };
+    std::vector<Cand> cands;
     for (int tile = 0; tile < 20; ++tile) {  // 4 tile shapes x 3 pipeline depths, then the 256-row / 256-column tiles
       int bm = 0, bn = 0, ns = 0;
       if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) continue;
@@ -403,66 +438,32 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
       if ((bm == 256 && p.M < 192) || (bn == 256 && p.N < 192)) continue;
       for (int sp : cand_splits) {
         if (sp > 1 && (geglu || (p.flags & GF_LNFOLD) || p.batch > 1 || p.nkb / sp < 2)) break;
-        GemmParams q = p;
-        q.kb_per_split = (p.nkb + sp - 1) / sp;
-        q.splits = (p.nkb + q.kb_per_split - 1) / q.kb_per_split;
-        if (q.splits != sp && sp > 1) continue;
-        const size_t need = dtp_gemm_workspace_bytes(q);
-        if (need > ((size_t)512 << 20)) continue;
-        if (need > c->ws_bytes) { c->ws_need = std::max(c->ws_need, need); RC(ensure_ws(c)); }
-        q.part = c->ws;
-        q.zero = c->zero;
-        // Time it the way the stamp sees it: weights COLD (1.7 GB of them stream through the 256 MiB
-        // Infinity Cache every UNet evaluation), activations warm (just written by the previous kernel).
-        float ms = 1e30f;  // best of 5: a single cold run is noisy (DVFS, thrash write-back still draining)
-        for (int rep = 0; rep < 5; ++rep) {
-          HIP_CHECK(hipMemsetAsync(c->tune_thrash, rep, THRASH_BYTES, 0));
-          RC(dtp_launch_touch(q.A, a_bytes, (float*)c->tune_thrash, 0));
-          if (q.R) RC(dtp_launch_touch(q.R, (size_t)q.M * q.ldr * 2, (float*)c->tune_thrash, 0));
-          HIP_CHECK(hipEventRecord(c->tune_ev[0], 0));
-          RC(dtp_launch_gemm(q, tile, 0));
-          HIP_CHECK(hipEventRecord(c->tune_ev[1], 0));
-          HIP_CHECK(hipEventSynchronize(c->tune_ev[1]));
-          float t = 0.f;
-          HIP_CHECK(hipEventElapsedTime(&t, c->tune_ev[0], c->tune_ev[1]));
-          ms = std::min(ms, t);
-        }
-        if (ms < best) { best = ms; bt = tile; bs = sp; }
+        float ms;
+        RC(time_cfg(tile, sp, 5, &ms));
+        if (ms >= 0.f) cands.push_back({ms, tile, sp});
       }
     }
-    // halo-tiled 3x3 variants (tile ids 12..15); their split-K runs over 64-channel blocks
     if (p.Wcb && dtp_conv_halo_supported(p)) {
       for (int v = 0; v < 4; ++v) {
         if ((v >= 2) != (p.Hi * p.Wi <= 256)) continue;  // 8x8 pixel tiles for small feature maps, 8x16 otherwise
         for (int sp : cand_splits) {
           if (sp > 1 && p.nkb / sp < 9) break;
-          GemmParams q = p;
-          q.W = p.Wcb;
-          q.kb_per_split = (p.nkb + sp - 1) / sp;
-          q.splits = (p.nkb + q.kb_per_split - 1) / q.kb_per_split;
-          if (q.splits != sp && sp > 1) continue;
-          const size_t need = dtp_gemm_workspace_bytes(q);
-          if (need > ((size_t)512 << 20)) continue;
-          if (need > c->ws_bytes) { c->ws_need = std::max(c->ws_need, need); RC(ensure_ws(c)); }
-          q.part = c->ws;
-          q.zero = c->zero;
-          float ms = 1e30f;
-          for (int rep = 0; rep < 5; ++rep) {
-            HIP_CHECK(hipMemsetAsync(c->tune_thrash, rep, THRASH_BYTES, 0));
-            RC(dtp_launch_touch(q.A, a_bytes, (float*)c->tune_thrash, 0));
-            if (q.R) RC(dtp_launch_touch(q.R, (size_t)q.M * q.ldr * 2, (float*)c->tune_thrash, 0));
-            HIP_CHECK(hipEventRecord(c->tune_ev[0], 0));
-            RC(dtp_launch_conv_halo(q, v, 0));
-            HIP_CHECK(hipEventRecord(c->tune_ev[1], 0));
-            HIP_CHECK(hipEventSynchronize(c->tune_ev[1]));
-            float t = 0.f;
-            HIP_CHECK(hipEventElapsedTime(&t, c->tune_ev[0], c->tune_ev[1]));
-            ms = std::min(ms, t);
-          }
-          if (ms < best) { best = ms; bt = 12 + v; bs = sp; }
+          float ms;
+          RC(time_cfg(12 + v, sp, 5, &ms));
+          if (ms >= 0.f) cands.push_back({ms, 12 + v, sp});
         }
       }
     }
+    // second round: the three fastest candidates are usually within the measurement noise of each other -- time them again,
+    // longer, and keep the minimum over both rounds
+    std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.ms < y.ms; });
+    for (size_t i = 0; i < cands.size() && i < 3; ++i) {
+      float ms;
+      RC(time_cfg(cands[i].tile, cands[i].sp, 8, &ms));
+      if (ms >= 0.f) cands[i].ms = std::min(cands[i].ms, ms);
+    }
+    for (size_t i = 0; i < cands.size() && i < 3; ++i)
+      if (cands[i].ms < best) { best = cands[i].ms; bt = cands[i].tile; bs = cands[i].sp; }
     it = c->tuned.emplace(key, std::make_pair(bt, bs)).first;
     if (getenv("DTP_TUNE_REPORT")) {  // how much of the chosen configuration's time is the cold operands?
       GemmParams q = p;
