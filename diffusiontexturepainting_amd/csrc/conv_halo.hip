@@ -22,6 +22,17 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_uniform) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Swizzle key of halo pixel (hy, hx): 16-byte chunk c of its 128-byte LDS row lives at chunk c ^ key.  The rows a ds_read_b128
+// lane group touches come from two image rows of the 18-wide halo of an 8x16 tile, shifted by the tap: with key = (hx >> 1) & 7
+// all 16 lanes of every group hit distinct slots of the 256-byte bank row for every tap (exhaustive check), whereas the GEMM
+// key (row >> 1) & 7 is 2-way conflicted there (+3..8 % on the level-0 convs).  The 8x8 tile keeps the row key: its
+// conflict-free key (hy + 4 * (hx >> 1)) & 7 measured 15-20 % SLOWER (more address arithmetic per fragment than it saves).
+template <int TW>
+__device__ __forceinline__ int halo_key(int hy, int hx) {
+  if constexpr (TW == 16) return (hx >> 1) & 7;
+  else return ((hy * (TW + 2) + hx) >> 1) & 7;
+}
+
 template <int TH, int TW, int BN>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
   constexpr int BM = TH * TW;                       // output pixels per workgroup (64 or 128)
@@ -68,14 +79,14 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
 #pragma unroll
   for (int i = 0; i < HL; ++i) {
     const int hp = (i * 4 + wave) * 8 + (lane >> 3);
-    const int kc = ((kc8 ^ ((hp >> 1) & 7)) << 3);
     const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
+    const int kc = ((kc8 ^ halo_key<TW>(hy, hx)) << 3);
     const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
     const bool ok = (hp < HP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
     hsrc[i] = ok ? p.A + ((size_t)(img * H + iy) * W + ix) * p.lda + kc : nullptr;
-    const int ty2 = y0 + hp / TW, tx2 = x0 + hp % TW;  // hp reinterpreted as a tile row
+    const int ty2 = y0 + hp / TW, tx2 = x0 + hp % TW;  // hp reinterpreted as a tile row (dense shortcut blocks: row key)
     const bool ok2 = p.A2 && (hp < BM) && (ty2 < H) && (tx2 < W);
-    tsrc[i] = ok2 ? p.A2 + ((size_t)(img * H + ty2) * W + tx2) * p.lda2 + kc : nullptr;
+    tsrc[i] = ok2 ? p.A2 + ((size_t)(img * H + ty2) * W + tx2) * p.lda2 + ((kc8 ^ ((hp >> 1) & 7)) << 3) : nullptr;
   }
   const int lrow = wave * 8 + (lane >> 3);
   const int wkc = ((kc8 ^ ((lrow >> 1) & 7)) << 3);
@@ -109,11 +120,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
 
   const int wn0 = (wave & 1) * (BN / 2), wm0 = (wave >> 1) * (BM / 2);
   const int frow = lane & 31, fhalf = lane >> 5;
-  int hbase[TM];  // halo row of this lane's output pixel for tap (0,0)
+  int hbase[TM], py[TM], px[TM];  // halo row / tile coordinates of this lane's output pixel for tap (0,0)
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int r = wm0 + j * 32 + frow;
-    hbase[j] = (r / TW) * (TW + 2) + (r % TW);
+    py[j] = r / TW; px[j] = r % TW;
+    hbase[j] = py[j] * (TW + 2) + px[j];
   }
 
   // ---- pipeline state for absolute k-block `it`: block id blk (channel block, or ncb + shortcut block), tap inside it
@@ -148,7 +160,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int row = tail ? (wm0 + j * 32 + frow) : (hbase[j] + hoff);
-        fr[ks % LA][j] = lds_read16(h_lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        const int key = tail ? ((row >> 1) & 7) : halo_key<TW>(py[j] + ky, px[j] + kx);
+        fr[ks % LA][j] = lds_read16(h_lds + row * 128 + ((c ^ key) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
