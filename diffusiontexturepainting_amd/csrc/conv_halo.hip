@@ -273,21 +273,22 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
   __syncthreads();
   const int fl = p.flags;
   constexpr int NC = BN / 8;
+  const int nc = tid % NC, n = n0 + nc * 8;  // loop-invariant (256 % NC == 0): the bias vector is loaded once
+  float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if ((fl & GF_BIAS) && n + 8 <= p.N) {
+    const f32x4 t0 = *(const f32x4*)(p.bias + n), t1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bv[e] = t0[e]; bv[4 + e] = t1[e]; }
+  }
   for (int idx = tid; idx < BM * NC; idx += 256) {
-    const int ml = idx / NC, nc = idx - ml * NC;
-    const int n = n0 + nc * 8;
+    const int ml = idx / NC;
     bool ok;
     const size_t m = row_m(ml, ok);
     if (!ok || n + 8 > p.N) continue;  // N % 8 == 0 is required by the launcher
     const f16x8 v = *(const f16x8*)(stg + ml * SLD + nc * 8);
     float x[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
-    if (fl & GF_BIAS) {
-      const f32x4 t0 = *(const f32x4*)(p.bias + n), t1 = *(const f32x4*)(p.bias + n + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { x[e] += t0[e]; x[4 + e] += t1[e]; }
-    }
+    for (int e = 0; e < 8; ++e) x[e] = (float)v[e] + bv[e];
     if (fl & GF_RESID) {
       const f16x8 r = *(const f16x8*)(p.R + m * p.ldr + n);
 #pragma unroll

@@ -364,32 +364,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
     // tile columns [0,BN/2) = a, [BN/2,BN) = gate of output features tile_n*BN/2 + ...
     constexpr int HC = BN / 16;  // 8-wide chunks per half
     f16* C = (f16*)p.C;
+    // a thread owns the same 8-column chunk in every iteration (256 % HC == 0): its bias / lns vectors are loaded once, as whole
+    // 16-byte vectors (per-element conditional loads make hipcc wait vmcnt(0) after every dword; N % 128 == 0 here)
+    const int nc = tid % HC;
+    float ba[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, la[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (fl & GF_BIAS) {
+      const f32x4 t0 = *(const f32x4*)(p.bias + n0 + nc * 8), t1 = *(const f32x4*)(p.bias + n0 + nc * 8 + 4);
+      const f32x4 u0 = *(const f32x4*)(p.bias + n0 + BN / 2 + nc * 8), u1 = *(const f32x4*)(p.bias + n0 + BN / 2 + nc * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ba[e] = t0[e]; ba[4 + e] = t1[e]; bg[e] = u0[e]; bg[4 + e] = u1[e]; }
+    }
+    if (fl & GF_LNFOLD) {
+      const f32x4 t0 = *(const f32x4*)(p.lns + n0 + nc * 8), t1 = *(const f32x4*)(p.lns + n0 + nc * 8 + 4);
+      const f32x4 u0 = *(const f32x4*)(p.lns + n0 + BN / 2 + nc * 8), u1 = *(const f32x4*)(p.lns + n0 + BN / 2 + nc * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { la[e] = t0[e]; la[4 + e] = t1[e]; lg[e] = u0[e]; lg[4 + e] = u1[e]; }
+    }
     for (int idx = tid; idx < BM * HC; idx += 256) {
-      const int ml = idx / HC, nc = idx - ml * HC;
+      const int ml = idx / HC;
       const int m = m0 + ml;
       if (m >= p.M) continue;
       const f16x8 a = *(const f16x8*)(stg + ml * SLD + nc * 8);
       const f16x8 g = *(const f16x8*)(stg + ml * SLD + BN / 2 + nc * 8);
-      // bias / lns are read as whole 16-byte vectors up front: per-element conditional loads make hipcc wait
-      // vmcnt(0) after every single dword (N % 128 == 0 here, so the vectors are always in range)
-      float ba[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, la[8], lg[8];
-      if (fl & GF_BIAS) {
-        const f32x4 t0 = *(const f32x4*)(p.bias + n0 + nc * 8), t1 = *(const f32x4*)(p.bias + n0 + nc * 8 + 4);
-        const f32x4 u0 = *(const f32x4*)(p.bias + n0 + BN / 2 + nc * 8), u1 = *(const f32x4*)(p.bias + n0 + BN / 2 + nc * 8 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { ba[e] = t0[e]; ba[4 + e] = t1[e]; bg[e] = u0[e]; bg[4 + e] = u1[e]; }
-      }
       float mean = 0.f, rstd = 1.f;
-      if (fl & GF_LNFOLD) {
-        const f32x4 t0 = *(const f32x4*)(p.lns + n0 + nc * 8), t1 = *(const f32x4*)(p.lns + n0 + nc * 8 + 4);
-        const f32x4 u0 = *(const f32x4*)(p.lns + n0 + BN / 2 + nc * 8), u1 = *(const f32x4*)(p.lns + n0 + BN / 2 + nc * 8 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { la[e] = t0[e]; la[4 + e] = t1[e]; lg[e] = u0[e]; lg[4 + e] = u1[e]; }
-        mean = rowst[2 * ml]; rstd = rowst[2 * ml + 1];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) la[e] = lg[e] = 0.f;
-      }
+      if (fl & GF_LNFOLD) { mean = rowst[2 * ml]; rstd = rowst[2 * ml + 1]; }
       f16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -404,9 +402,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
 
   constexpr int NC = BN / 8;
   const bool vec_ok = ((p.ldc & 7) == 0) && !(fl & GF_OUT_F32) && (!(fl & GF_RESID) || (p.ldr & 7) == 0);
+  // A thread owns the same 8-column chunk in every iteration (256 % NC == 0): its per-column vectors (bias, lns) are loaded once,
+  // as whole 16-byte loads when the chunk is complete, guarded scalars on the N tail.
+  const int nc = tid % NC, n = n0 + nc * 8;
+  const bool full = (n + 8 <= p.N);
+  float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (full) {
+    if (fl & GF_BIAS) {
+      const f32x4 t0 = *(const f32x4*)(p.bias + n), t1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bv[e] = t0[e]; bv[4 + e] = t1[e]; }
+    }
+    if (fl & GF_LNFOLD) {
+      const f32x4 t0 = *(const f32x4*)(p.lns + n), t1 = *(const f32x4*)(p.lns + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lv[e] = t0[e]; lv[4 + e] = t1[e]; }
+    }
+  } else {
+    for (int e = 0; e < 8 && n + e < p.N; ++e) {
+      if (fl & GF_BIAS) bv[e] = p.bias[n + e];
+      if (fl & GF_LNFOLD) lv[e] = p.lns[n + e];
+    }
+  }
   for (int idx = tid; idx < BM * NC; idx += 256) {  // BM*NC is a multiple of 256: every lane runs every iteration
-    const int ml = idx / NC, nc = idx - ml * NC;
-    const int m = m0 + ml, n = n0 + nc * 8;
+    const int ml = idx / NC;
+    const int m = m0 + ml;
     const bool active = (m < p.M) && (n < p.N);
     float s1 = 0.f, s2 = 0.f;
     if (active) {
@@ -414,26 +434,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
       float x[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
-      const bool full = (n + 8 <= p.N);
-      // per-column vectors (bias, lns) as whole 16-byte loads when the chunk is complete; guarded scalars on the N tail
-      float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (full) {
-        if (fl & GF_BIAS) {
-          const f32x4 t0 = *(const f32x4*)(p.bias + n), t1 = *(const f32x4*)(p.bias + n + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { bv[e] = t0[e]; bv[4 + e] = t1[e]; }
-        }
-        if (fl & GF_LNFOLD) {
-          const f32x4 t0 = *(const f32x4*)(p.lns + n), t1 = *(const f32x4*)(p.lns + n + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { lv[e] = t0[e]; lv[4 + e] = t1[e]; }
-        }
-      } else {
-        for (int e = 0; e < 8 && n + e < p.N; ++e) {
-          if (fl & GF_BIAS) bv[e] = p.bias[n + e];
-          if (fl & GF_LNFOLD) lv[e] = p.lns[n + e];
-        }
-      }
       if (fl & GF_LNFOLD) {
         const float mean = rowst[2 * ml], rstd = rowst[2 * ml + 1];
 #pragma unroll
