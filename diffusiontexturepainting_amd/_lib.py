@@ -28,7 +28,7 @@ PROF_KINDS = [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 
     ["attention_kernel", "groupnorm (gn_stats+gn_apply | gn_fused)", "layernorm_kernel", "concat_kernel / small elementwise",
      "softmax_rows_kernel", "conv_halo_kernel<8, 16, 64>", "conv_halo_kernel<8, 16, 128>", "conv_halo_kernel<8, 8, 64>",
      "conv_halo_kernel<8, 8, 128>", "gemm_kernel<256, 128, 2>", "gemm_kernel<256, 128, 3>", "gemm_kernel<128, 256, 2>",
-     "gemm_kernel<128, 256, 3>"]
+     "gemm_kernel<128, 256, 3>", "gemm_wide_kernel<256, 256>", "gemm_wide_kernel<256, 320>"]
 
 
 class GemmDesc(C.Structure):
@@ -40,11 +40,13 @@ class GemmDesc(C.Structure):
                 ("flags", C.c_int), ("tile", C.c_int), ("splits", C.c_int), ("lns", C.c_void_p), ("ln_eps", C.c_float),
                 ("A2", C.c_void_p), ("lda2", C.c_int), ("Cin2", C.c_int), ("Wcb", C.c_void_p),
                 ("batch", C.c_int), ("a_bs", C.c_int64), ("w_bs", C.c_int64), ("c_bs", C.c_int64), ("r_bs", C.c_int64),
-                ("bias_bs", C.c_int), ("lns_bs", C.c_int), ("sm_valid", C.c_int)]
+                ("bias_bs", C.c_int), ("lns_bs", C.c_int), ("sm_valid", C.c_int),
+                ("st_out", C.c_void_p), ("st_in", C.c_void_p), ("st_parts", C.c_int), ("st_parts_out", C.c_int)]
 
 
 GF_BIAS, GF_BIAS_M, GF_RESID, GF_GEGLU, GF_GELU, GF_QUICKGELU, GF_OUT_F32, GF_SILU, GF_LNFOLD = 1, 2, 4, 8, 64, 128, 256, 512, 1024
 GF_SOFTMAX16 = 4096
+GF_ROWSTATS = 2048
 
 # every symbol include/dtp.h declares: name -> (restype, argtypes)
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -69,6 +71,7 @@ SYMBOLS = {
     "dtp_profile_rows": (_i, [_vp, C.POINTER(ProfRow), _i, C.POINTER(_i)]),
     "dtp_profile_dump": (_i, [_vp, C.c_char_p]),
     "dtp_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "dtp_last_stamp_finite": (_i, [_vp, C.POINTER(_i)]),
     "dtp_op_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "dtp_op_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dtp_op_pack_conv": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -78,6 +81,7 @@ SYMBOLS = {
     "dtp_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
     "dtp_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp]),
     "dtp_op_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
+    "dtp_op_dilate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 
 

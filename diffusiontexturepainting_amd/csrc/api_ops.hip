@@ -59,12 +59,12 @@ extern "C" {
 int dtp_abi_version(void) { return DTP_ABI_VERSION; }
 const char* dtp_last_error(void) { return g_err; }
 
-int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s) {
+int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
   std::lock_guard<std::mutex> lk(g_ops_mu);
   int rc = ops_init();
   if (rc) return rc;
   static bool halo_init = false;
-  if (!halo_init) { dtp_conv_halo_init(); halo_init = true; }
+  if (!halo_init) { dtp_conv_halo_init(); dtp_gemm_wide_init(); halo_init = true; }
   GemmParams p = {};
   p.A = (const f16*)d->A; p.W = (const f16*)d->W; p.C = d->C; p.bias = d->bias; p.R = (const f16*)d->R;
   p.zero = g_ops.zero;
@@ -77,6 +77,7 @@ int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s) {
   p.A2 = (const f16*)d->A2; p.lda2 = d->lda2; p.Cin2 = d->Cin2;
   p.batch = d->batch; p.a_bs = d->a_bs; p.w_bs = d->w_bs; p.c_bs = d->c_bs; p.r_bs = d->r_bs;
   p.bias_bs = d->bias_bs; p.lns_bs = d->lns_bs; p.sm_valid = d->sm_valid;
+  p.st_out = d->st_out; p.st_in = d->st_in; p.st_parts = d->st_parts;
   if (p.ldw < p.nkb * 64) { dtp_set_error("gemm: ldw=%d smaller than padded K=%d", p.ldw, p.nkb * 64); return DTP_ERR_ARG; }
   int tile = 0;
   dtp_gemm_pick(p, &tile, g_ops.num_cu);
@@ -85,6 +86,7 @@ int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s) {
     p.kb_per_split = (p.nkb + d->splits - 1) / d->splits;
     p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
   }
+  if (tile >= 20) { p.splits = 1; p.kb_per_split = p.nkb; }  // the wide tiles are unsplit
   if (tile >= 12 && tile < 16) {  // halo-tiled 3x3 conv: split-K counts 64-channel blocks
     if (!d->Wcb) { dtp_set_error("conv_halo: Wcb missing"); return DTP_ERR_ARG; }
     p.W = (const f16*)d->Wcb;
@@ -95,6 +97,11 @@ int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s) {
   rc = ops_ws(dtp_gemm_workspace_bytes(p));
   if (rc) return rc;
   p.part = g_ops.ws;
+  if (p.flags & GF_ROWSTATS) {
+    int bm = 0, bn = 64, ns = 0;
+    (void)dtp_gemm_tile_dims(tile, &bm, &bn, &ns);
+    d->st_parts_out = p.splits > 1 ? 1 : (p.N + bn - 1) / bn;
+  }
   if (tile >= 12 && tile < 16) return dtp_launch_conv_halo(p, tile - 12, (hipStream_t)s);
   return dtp_launch_gemm(p, tile, (hipStream_t)s);
 }

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/dtp.h"
+
 typedef _Float16 f16;
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
@@ -28,12 +30,16 @@ static __device__ __forceinline__ f16x8 lds_read16(uint32_t addr) {
 // s_waitcnt lgkmcnt(N) that the NF fragments "pass through", so their consumers cannot be scheduled above the wait
 template <int N, int NF>
 static __device__ __forceinline__ void wait_lds_frags(f16x8 (&f)[NF]) {
-  static_assert(NF == 2 || NF == 3 || NF == 4 || NF == 6 || NF == 8, "fragment count");
+  static_assert(NF == 2 || NF == 3 || NF == 4 || NF == 6 || NF == 7 || NF == 8, "fragment count");
   if constexpr (NF == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(N));
   else if constexpr (NF == 3) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : "n"(N));
   else if constexpr (NF == 4) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N));
   else if constexpr (NF == 6)
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(N));
+  else if constexpr (NF == 7)
+    asm volatile("s_waitcnt lgkmcnt(%7)"
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6])
+                 : "n"(N));
   else
     asm volatile("s_waitcnt lgkmcnt(%8)"
                  : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])
@@ -41,6 +47,19 @@ static __device__ __forceinline__ void wait_lds_frags(f16x8 (&f)[NF]) {
 }
 
 
+
+// exact (erf) GELU.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 output): one v_rcp, one v_exp and
+// a degree-5 Horner chain instead of the ~3x longer libm erff, which showed up in the GEGLU epilogues (2.6 G evaluations / stamp)
+static __device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  float pl = fmaf(1.061405429f, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  const float e = 1.0f - pl * t * __expf(-z * z);  // erf(|x| / sqrt 2)
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
 
 #define DTP_WAVE 64
 
@@ -53,7 +72,7 @@ static __device__ __forceinline__ void wait_lds_frags(f16x8 (&f)[NF]) {
     }                                                                                       \
   } while (0)
 
-enum { DTP_OK = 0, DTP_ERR_ARG = 1, DTP_ERR_HIP = 2, DTP_ERR_STATE = 3, DTP_ERR_MISSING = 4 };
+// error codes: include/dtp.h (DTP_OK, DTP_ERR_*)
 
 void dtp_set_error(const char* fmt, ...);
 
@@ -150,6 +169,10 @@ int dtp_launch_matmul_f32(const float* A, const float* B, float* C, int M, int N
 int dtp_launch_expand_kv(const f16* kv, f16* kexp, f16* vexp, int N, int T, int C, int H, float scale, hipStream_t s);
 int dtp_launch_transpose_f16(const f16* src, int lds_, f16* dst, int ldd, int rows, int cols, hipStream_t s);
 int dtp_launch_rowdot_f16(const f16* a, int ld, const float* v, float* out, int rows, int K, hipStream_t s);
+// gemm_wide.hip: 8-wave wide tiles; variant 0 = 256x256, 1 = 256x320 (tile ids 20 / 21 of dtp_launch_gemm)
+bool dtp_gemm_wide_supported(const GemmParams& p, int variant);
+int dtp_launch_gemm_wide(const GemmParams& p, int variant, hipStream_t s);
+void dtp_gemm_wide_init();
 // conv_halo.hip: variant 0..3 = (8x16|8x8 pixel tile) x (64|128 output channels); kb_per_split counts 64-channel blocks
 bool dtp_conv_halo_supported(const GemmParams& p);
 int dtp_launch_conv_halo(const GemmParams& p, int variant, hipStream_t s);

@@ -47,7 +47,7 @@ struct Ctx;
 // A launch program: a flat list of closures bound to statically planned buffers.
 using Op = std::function<int(hipStream_t, int /*step*/)>;
 // profiling classes (dtp_profile_rows): 0-11 = gemm_kernel<BM,BN,NS> variants (id = shape + 4*(NS-2)), then the rest
-enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_BIG0 = 21, PK_COUNT = 25 };
+enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_BIG0 = 21, PK_WIDE0 = 25, PK_COUNT = 27 };
 struct ProfRec {
   int kind;
   double flops, bytes;
@@ -139,6 +139,10 @@ struct UNetProg {
   std::vector<f16*> xW1, xW2;
   std::vector<float*> xb1, xl1;
   f16 *kexp = nullptr, *vexp = nullptr;  // scratch [N*128][1280]
+  // validity of ctx16 / the per-stamp cross-attention matrices: the layout [uncond x B | cond x (NB-1)B] depends on the
+  // (B, NB) split, not only on N = NB*B (B=2,NB=3 and B=3,NB=2 share a program)
+  unsigned long long kv_ver = 0;
+  int kv_B = 0, kv_NB = 0;
 };
 struct VaeEncProg {
   int B = 0;
@@ -151,6 +155,17 @@ struct VaeDecProg {
   Prog main;
   f16* in8 = nullptr;     // [B][h][w][8] (after post_quant_conv)
   float* out32 = nullptr; // [B][R][R][4] (3 used)
+};
+
+struct StampBufs {  // per-batch persistent staging of dtp_stamp
+  float *masks = nullptr, *ml = nullptr, *lat = nullptr, *eps = nullptr;
+};
+struct IencBufs {  // brush-encoder program + buffers (built on the first dtp_set_brush)
+  float* img224 = nullptr;
+  f16* patchA = nullptr;
+  Prog prog;
+  f16* out16 = nullptr;  // [14][768] final embeddings (f16)
+  bool built = false;
 };
 
 struct StampGraph {
@@ -195,13 +210,17 @@ struct Ctx {
   float* brush32 = nullptr;  // [3][R][R]
   bool have_cond = false;
   unsigned long long cond_version = 0;
-  std::map<int, unsigned long long> kv_version;  // per UNet batch: conditioning version its K/V were built from
 
   // stamp state
   float* x32 = nullptr;       // [maxB][h][w][4] current latent (fp32, NHWC)
   float* canvas32 = nullptr;  // [maxB][4][R][R] copy of the canvas (for compositing inside the graph-free tail)
   float* alpha_tmp = nullptr; // dilation scratch [2][maxB][R][R]
   float* stamp_params = nullptr;  // device: per-step DDIM coefficients + weights
+  std::map<int, StampBufs> stamp_bufs;  // keyed by stamp batch B; the buffers live in `persistent` and die with the context
+  IencBufs ienc_bufs;
+  int* finite_flag = nullptr;     // device: set to 1 by the post-loop finiteness check ("check_finite" option)
+  bool check_finite = false;
+  bool finite_pending = false;    // the last stamp ran the check; dtp_last_stamp_finite reads the flag
   std::map<long long, StampGraph> graphs;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int last_evals = 0, last_nodes = 0;

@@ -348,18 +348,42 @@ int Builder::ln(const T& x, const NormW& n, T& y) {
 }
 
 void prog_push(Ctx* c, Prog* prog, int kind, double flops, double bytes, Op fn, const std::string& label);
-void tune_cache_load(Ctx* c) {
-  const char* e = getenv("DTP_TUNE_CACHE");
-  if (!e || !*e) return;
-  c->tune_cache_path = e;
-  FILE* f = fopen(e, "r");
+static void tune_read_file(Ctx* c, const char* path) {
+  FILE* f = fopen(path, "r");
   if (!f) return;
   char key[256];
   int tile, splits;
   while (fscanf(f, "%255s %d %d", key, &tile, &splits) == 3)
-    if (tile >= 0 && tile < 20 && splits >= 1 && splits <= 64) c->tuned[key] = std::make_pair(tile, splits);
+    if (tile >= 0 && tile < 32 && splits >= 1 && splits <= 64) c->tuned[key] = std::make_pair(tile, splits);
   fclose(f);
+}
+
+// $DTP_TUNE_SEED: a read-only table shipped with the package (the choices measured on the build's own MI355X), read first;
+// $DTP_TUNE_CACHE: the per-user table this process may extend.  Entries are only trusted after tune_entry_valid().
+void tune_cache_load(Ctx* c) {
+  const char* seed = getenv("DTP_TUNE_SEED");
+  if (seed && *seed) tune_read_file(c, seed);
+  const char* e = getenv("DTP_TUNE_CACHE");
+  if (!e || !*e) return;
+  c->tune_cache_path = e;
+  tune_read_file(c, e);
   c->tune_saved = c->tuned.size();
+}
+
+// Is (tile, splits) a configuration the launcher accepts for THIS problem?  A persisted table can be stale (older build,
+// different packing) or hand-edited: a halo tile without the channel-block-major packing, a GEGLU problem on a tile that is
+// not 128 wide, or a split LayerNorm-fold would otherwise reach the kernels.
+static bool tune_entry_valid(const GemmParams& p, int tile, int sp) {
+  if (sp < 1 || sp > p.nkb) return false;
+  const bool halo = tile >= 12 && tile < 16;
+  if (halo) return p.Wcb && dtp_conv_halo_supported(p) && p.batch <= 1;
+  int bm = 0, bn = 0, ns = 0;
+  if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) return false;
+  if (tile >= 20) { GemmParams q = p; q.splits = 1; return sp == 1 && dtp_gemm_wide_supported(q, tile - 20); }
+  if ((p.flags & GF_GEGLU) && (bn != 128 || sp != 1)) return false;
+  if (sp > 1 && ((p.flags & (GF_LNFOLD | GF_SOFTMAX16)) || p.batch > 1)) return false;
+  if ((size_t)sp * p.M * p.N * sizeof(float) > ((size_t)512 << 20)) return false;
+  return true;
 }
 
 void tune_cache_save(Ctx* c) {
@@ -381,11 +405,16 @@ void tune_cache_save(Ctx* c) {
 // with every tile variant x split-K factor on the real buffers and the fastest pair is kept.
 static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   char key[200];
-  // "k3|": bump when tile ids or pipelines change, so that a persisted table written by an older build is ignored
-  int kl = snprintf(key, sizeof(key), "k3|%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
+  // "k4|": bump when tile ids or pipelines change, so that a persisted table written by an older build is ignored
+  int kl = snprintf(key, sizeof(key), "k4|%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
                     p.stride, p.lda, p.ldc, p.ldw, p.st_parts, p.Cin2, p.lda2);
   if (p.batch > 1) snprintf(key + kl, sizeof(key) - kl, ",b%d", p.batch);
   auto it = c->tuned.find(key);
+  if (it != c->tuned.end() && !tune_entry_valid(p, it->second.first, it->second.second)) {
+    fprintf(stderr, "[dtp] tune table entry '%s' -> (%d, %d) does not fit the problem; re-tuning\n", key, it->second.first, it->second.second);
+    c->tuned.erase(it);
+    it = c->tuned.end();
+  }
   if (it == c->tuned.end()) {
     if (!c->tune_ev[0]) { HIP_CHECK(hipEventCreate(&c->tune_ev[0])); HIP_CHECK(hipEventCreate(&c->tune_ev[1])); }
     constexpr size_t THRASH_BYTES = (size_t)512 << 20;
@@ -430,9 +459,20 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     };
     struct Cand { float ms; int tile, sp; };
     std::vector<Cand> cands;
-    for (int tile = 0; tile < 20; ++tile) {  // 4 tile shapes x 3 pipeline depths, then the 256-row / 256-column tiles
+    for (int tile = 0; tile < 22; ++tile) {  // 4 tile shapes x 3 pipeline depths, the 256-row / 256-column tiles, the 8-wave wide tiles
       int bm = 0, bn = 0, ns = 0;
       if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) continue;
+      if (tile >= 20) {  // gemm_wide_kernel: unsplit big-M problems only (at least half a wave of 256 CUs worth of tiles)
+        GemmParams q = p;
+        q.splits = 1;
+        if (!dtp_gemm_wide_supported(q, tile - 20)) continue;
+        if ((long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) < 96) continue;
+        if (tile == 21 && (p.N % 320) > 0 && (p.N % 320) <= 192) continue;  // a mostly empty last column tile: 256 x 256 covers it better
+        float ms;
+        RC(time_cfg(tile, 1, 5, &ms));
+        if (ms >= 0.f) cands.push_back({ms, tile, 1});
+        continue;
+      }
       if (geglu && bn != 128) continue;
       if (p.nkb < 3 && ns > 2) continue;
       if ((bm == 256 && p.M < 192) || (bn == 256 && p.N < 192)) continue;
@@ -522,7 +562,7 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
            p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? " geglu" : "", p.stride == 2 ? " s2" : "",
            p.batch > 1 ? (" x" + std::to_string(p.batch)).c_str() : "");
-  prog_push(c, prog, tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile, 2.0 * nb * p.M * (double)p.N * k_alg, bytes, [=](hipStream_t s, int step) {
+  prog_push(c, prog, tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile, 2.0 * nb * p.M * (double)p.N * k_alg, bytes, [=](hipStream_t s, int step) {
     GemmParams q = p;
     q.part = c->ws;
     if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;

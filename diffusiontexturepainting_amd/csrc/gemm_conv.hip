@@ -27,19 +27,6 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_uniform) {
                                    (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
 }
 
-// exact (erf) GELU.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 output): one v_rcp, one v_exp and
-// a degree-5 Horner chain instead of the ~3x longer libm erff, which showed up in the GEGLU epilogues (2.6 G evaluations / stamp)
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-  float pl = fmaf(1.061405429f, t, -1.453152027f);
-  pl = fmaf(pl, t, 1.421413741f);
-  pl = fmaf(pl, t, -0.284496736f);
-  pl = fmaf(pl, t, 0.254829592f);
-  const float e = 1.0f - pl * t * __expf(-z * z);  // erf(|x| / sqrt 2)
-  return 0.5f * x * (1.0f + copysignf(e, x));
-}
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -579,12 +566,14 @@ void dtp_gemm_init() {  // raise the dynamic-LDS limit once, outside any stream 
 #undef SET_ATTR
 }
 
+// 20 / 21: gemm_wide_kernel 256 x 256 / 256 x 320 (gemm_wide.hip).
 // tile id -> (BM, BN, pipeline depth).  0..11: shape (id & 3) of {128x128, 128x64, 64x64, 64x128} at depth 2 + id / 4;
 // 16..19: the big tiles {256x128, 256x128, 128x256, 128x256} at depth {2, 3, 2, 3}.  (12..15 are the halo conv kernels.)
 bool dtp_gemm_tile_dims(int tile, int* bm, int* bn, int* ns) {
   static const int sm[4] = {128, 128, 64, 64}, sn[4] = {128, 64, 64, 128};
   if (tile >= 0 && tile < 12) { *bm = sm[tile & 3]; *bn = sn[tile & 3]; *ns = 2 + (tile >> 2); return true; }
   if (tile >= 16 && tile < 20) { *bm = tile < 18 ? 256 : 128; *bn = tile < 18 ? 128 : 256; *ns = 2 + (tile & 1); return true; }
+  if (tile == 20 || tile == 21) { *bm = 256; *bn = tile == 20 ? 256 : 320; *ns = 2; return true; }  // gemm_wide_kernel (8 waves)
   return false;
 }
 
@@ -620,6 +609,7 @@ void dtp_gemm_pick(GemmParams& p, int* tile, int num_cu) {
 
 int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
   if (p.nkb <= 0 || p.M <= 0 || p.N <= 0) { dtp_set_error("gemm: empty problem"); return DTP_ERR_ARG; }
+  if (tile == 20 || tile == 21) return dtp_launch_gemm_wide(p, tile - 20, s);
   if ((p.lda & 7) || (p.ldw & 7)) { dtp_set_error("gemm: lda/ldw must be multiples of 8"); return DTP_ERR_ARG; }
   if ((p.flags & GF_CONV3) && (p.Cin & 7)) { dtp_set_error("conv: Cin must be a multiple of 8"); return DTP_ERR_ARG; }
   if (p.A2 && (p.flags & GF_CONV3) && (((9 * p.Cin) & 63) || (p.Cin2 & 63) || (p.lda2 & 7) || p.stride != 1)) {

@@ -13,7 +13,8 @@ namespace {
 // torchvision CenterCrop(min side) + Resize(R): bilinear, align_corners=False, no antialias
 __global__ void crop_resize_kernel(const float* __restrict__ img, int H, int W, float* __restrict__ out, int R) {
   const int m = min(H, W);
-  const int top = (int)roundf((H - m) / 2.0f), left = (int)roundf((W - m) / 2.0f);
+  // torchvision center_crop: int(round((H - m) / 2.0)) with Python's round-half-to-even
+  const int top = (int)rintf((H - m) / 2.0f), left = (int)rintf((W - m) / 2.0f);
   const float scale = (float)m / (float)R;
   const int total = 3 * R * R;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
@@ -121,15 +122,6 @@ __global__ void add_table_kernel(f16* __restrict__ x, const float* __restrict__ 
 __global__ void f16_to_f32_kernel(const f16* __restrict__ x, float* __restrict__ y, int n) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[i] = (float)x[i];
 }
-
-struct IencBufs {
-  float* img224 = nullptr;
-  f16* patchA = nullptr;
-  Prog prog;
-  f16* out16 = nullptr;  // [14][768] final embeddings (f16)
-  bool built = false;
-};
-std::map<Ctx*, IencBufs> g_ienc;
 
 T rows_view(f16* p, int rows, int C, int ld) {
   T t;
@@ -325,7 +317,7 @@ extern "C" int dtp_set_brush(dtp_ctx* ctx, const float* image, int H, int W, flo
   if (!c->ienc.present) { dtp_set_error("dtp_set_brush: image-encoder weights (clip.*, penc.*) were not loaded"); return DTP_ERR_STATE; }
   if (!image || H < 1 || W < 1) { dtp_set_error("dtp_set_brush: bad image"); return DTP_ERR_ARG; }
   HIP_CHECK(hipSetDevice(c->device));
-  IencBufs& ib = g_ienc[c];
+  IencBufs& ib = c->ienc_bufs;
   if (!ib.built) RC(build_ienc(c, ib));
   const int R = c->R;
   hipLaunchKernelGGL(crop_resize_kernel, dim3(1024), dim3(256), 0, s, image, H, W, c->brush32, R);

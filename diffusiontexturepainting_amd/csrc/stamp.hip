@@ -16,13 +16,16 @@ int launch_post_quant(Ctx* c, const float* z, int nhwc, float in_scale, f16* out
 int load_imgenc_weights(Ctx* c);
 void dtp_gemm_init();
 void dtp_conv_halo_init();
+void dtp_gemm_wide_init();
 
 #define VAE_SCALE 0.18215f
 
 // ---------------------------------------------------------------- DDIM tables (host, fp32 like torch)
 // utilities.py:383-388 (betas, cumprod), :432-439 (timesteps), :416 (gather), :397 (final alpha).
 extern "C" int dtp_ddim_tables(int steps, int64_t* timesteps, float* alphas, float* final_alpha) {
-  if (steps < 1 || steps > 1000) { dtp_set_error("ddim: steps %d outside 1..1000", steps); return DTP_ERR_ARG; }
+  // the largest timestep is (steps-1)*(1000/steps) + 1: steps = 1000 would index alphas_cumprod[1000] (the reference raises
+  // IndexError there, utilities.py:416)
+  if (steps < 1 || steps > 999) { dtp_set_error("ddim: steps %d outside 1..999", steps); return DTP_ERR_ARG; }
   const int T = 1000;
   static float full[1000];
   static bool have = false;
@@ -200,6 +203,24 @@ __global__ void build_ctx_kernel(const float* __restrict__ cond2, f16* __restric
   }
 }
 
+// cfg / tg / tg_steps travel as kernel ARGUMENTS into the device parameter block the captured step kernels read: no host
+// staging buffer, so dtp_stamp never has to wait for the stream
+__global__ void set_header_kernel(float* __restrict__ params, float cfg, float tg, float tg_steps) {
+  if (threadIdx.x == 0) { params[0] = cfg; params[1] = tg; params[2] = tg_steps; params[3] = 0.f; }
+}
+
+// post-loop finiteness guard (the reference asserts `not isnan` after every step, stable_diffusion_pipeline.py:415, at the
+// price of a host sync per step; here ONE pass over the final latents and the decoded image, debug option "check_finite")
+__global__ void finite_check_kernel(const float* __restrict__ a, long long na, const float* __restrict__ b, long long nb,
+                                    int* __restrict__ flag) {
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < na + nb; i += (long long)gridDim.x * 256) {
+    const float v = i < na ? a[i] : b[i - na];
+    bad |= !(fabsf(v) <= 3.0e38f);  // false for NaN and +-inf
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 inline int nblk(long long total) { return (int)std::min<long long>((total + 255) / 256, 4096); }
 
 }  // namespace
@@ -215,18 +236,13 @@ int stamp_init(Ctx* c) {
   RC(ctx_persistent(c, (4 + 4 * 1000) * 4, &p, true)); c->stamp_params = (float*)p;
   RC(ctx_persistent(c, 2 * 14 * 768 * 4, &p, true)); c->cond32 = (float*)p;
   RC(ctx_persistent(c, 3 * RR * 4, &p, true)); c->brush32 = (float*)p;
+  RC(ctx_persistent(c, 256, &p, true)); c->finite_flag = (int*)p;
   return DTP_OK;
 }
 
-struct StampBufs {  // per-batch persistent staging
-  float *masks = nullptr, *ml = nullptr, *lat = nullptr, *eps = nullptr;
-};
-static std::map<std::pair<Ctx*, int>, StampBufs> g_bufs;
-
 static int get_bufs(Ctx* c, int B, StampBufs** out) {
-  auto key = std::make_pair(c, B);
-  auto it = g_bufs.find(key);
-  if (it == g_bufs.end()) {
+  auto it = c->stamp_bufs.find(B);
+  if (it == c->stamp_bufs.end()) {
     StampBufs sb;
     void* p;
     const size_t hw = (size_t)c->h * c->h;
@@ -234,7 +250,7 @@ static int get_bufs(Ctx* c, int B, StampBufs** out) {
     RC(ctx_persistent(c, 2 * B * 4 * hw * 4, &p, true)); sb.ml = (float*)p;
     RC(ctx_persistent(c, B * 4 * hw * 4, &p, true)); sb.lat = (float*)p;
     RC(ctx_persistent(c, 2 * B * 4 * hw * 4, &p, true)); sb.eps = (float*)p;
-    it = g_bufs.emplace(key, sb).first;
+    it = c->stamp_bufs.emplace(B, sb).first;
   }
   *out = &it->second;
   return DTP_OK;
@@ -265,6 +281,16 @@ static int run_stage(Ctx* c, long long key, hipStream_t s, F body) {
 
 extern "C" {
 
+// kernel-level entry point: the separable flat dilation of add_extra_context (handler.py:28-29) on the alpha plane of a canvas
+int dtp_op_dilate(const float* canvas, float* tmp, float* out, int B, int R, int pad, dtp_stream s_) {
+  if (!canvas || !tmp || !out || B < 1 || R < 1 || pad < 1) { dtp_set_error("dtp_op_dilate: bad argument"); return DTP_ERR_ARG; }
+  hipStream_t s = (hipStream_t)s_;
+  const int lo = pad / 2, hi = pad - pad / 2 - 1;
+  hipLaunchKernelGGL(dilate_row_kernel, dim3(nblk((long long)B * R * R)), dim3(256), 0, s, canvas, tmp, B, R, lo, hi);
+  hipLaunchKernelGGL(dilate_col_kernel, dim3(nblk((long long)B * R * R)), dim3(256), 0, s, tmp, out, B, R, lo, hi);
+  return LAUNCH_OK();
+}
+
 int dtp_finalize_weights(dtp_ctx* ctx) {
   Ctx* c = (Ctx*)ctx;
   if (!c) { dtp_set_error("dtp_finalize_weights: null handle"); return DTP_ERR_ARG; }
@@ -272,6 +298,7 @@ int dtp_finalize_weights(dtp_ctx* ctx) {
   HIP_CHECK(hipSetDevice(c->device));
   dtp_gemm_init();
   dtp_conv_halo_init();
+  dtp_gemm_wide_init();
   RC(load_unet_weights(c));
   RC(load_vae_weights(c));
   bool has_clip = false;
@@ -315,7 +342,7 @@ int dtp_stamp(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const f
   if (!c || !c->finalized) { dtp_set_error("dtp_stamp: weights not finalized"); return DTP_ERR_STATE; }
   if (!c->have_cond) { dtp_set_error("dtp_stamp: no brush set (call dtp_set_brush / dtp_set_conditioning)"); return DTP_ERR_STATE; }
   if (!canvas || !st || !latents || !out || B < 1 || B > c->maxB) { dtp_set_error("dtp_stamp: bad argument (B=%d, max %d)", B, c->maxB); return DTP_ERR_ARG; }
-  if (st->steps < 2 || st->steps > 1000) { dtp_set_error("dtp_stamp: steps=%d outside 2..1000", st->steps); return DTP_ERR_ARG; }
+  if (st->steps < 2 || st->steps > 999) { dtp_set_error("dtp_stamp: steps=%d outside 2..999", st->steps); return DTP_ERR_ARG; }
   if (st->context_pad < 1) { dtp_set_error("dtp_stamp: context_pad must be >= 1"); return DTP_ERR_ARG; }
   HIP_CHECK(hipSetDevice(c->device));
   const int R = c->R, h = c->h, HW = R * R, HWl = h * h;
@@ -334,7 +361,7 @@ int dtp_stamp(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const f
   RC(get_bufs(c, B, &sb));
 
   // ---- schedule tables (update_infer_settings, inpaint_pipeline.py:39-50): rebuilt when the step count changes
-  if (c->sched_steps != steps) {
+  if (c->sched_steps != steps) {  // rare (a settings change): the only host-blocking part of dtp_stamp
     HIP_CHECK(hipStreamSynchronize(s));
     std::vector<int64_t> ts(steps);
     std::vector<float> al(steps);
@@ -355,18 +382,16 @@ int dtp_stamp(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const f
     HIP_CHECK(hipMemcpy(c->stamp_params + 4, k.data(), k.size() * 4, hipMemcpyHostToDevice));
     c->sched_steps = steps;
   }
-  const float hdr[4] = {st->cfg_weight, st->tg_weight, (float)st->tg_steps, 0.f};
-  HIP_CHECK(hipMemcpyAsync(c->stamp_params, hdr, sizeof(hdr), hipMemcpyHostToDevice, s));
-  HIP_CHECK(hipStreamSynchronize(s));  // hdr is a stack buffer
+  hipLaunchKernelGGL(set_header_kernel, dim3(1), dim3(64), 0, s, c->stamp_params, st->cfg_weight, st->tg_weight, (float)st->tg_steps);
 
   // ---- cross-attention K/V for the current brush
   for (UNetProg* up : {u3, u2}) {
     if (!up) continue;
-    if (c->kv_version[up->N] != c->cond_version) {
-      const int NB = up->N / B;
+    const int NB = up->N / B;
+    if (up->kv_ver != c->cond_version || up->kv_B != B || up->kv_NB != NB) {
       hipLaunchKernelGGL(build_ctx_kernel, dim3(nblk((long long)up->N * 14 * 768)), dim3(256), 0, s, c->cond32, up->ctx16, B, NB);
       RC(up->kv.run(s, 0));
-      c->kv_version[up->N] = c->cond_version;
+      up->kv_ver = c->cond_version; up->kv_B = B; up->kv_NB = NB;
     }
   }
 
@@ -417,8 +442,25 @@ int dtp_stamp(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const f
   }));
   hipLaunchKernelGGL(finish_kernel, dim3(nblk((long long)B * HW)), dim3(256), 0, s, dec->out32, c->canvas32, out, B, HW,
                      st->composite, st->output_u8);
+  c->finite_pending = c->check_finite;
+  if (c->check_finite) {
+    HIP_CHECK(hipMemsetAsync(c->finite_flag, 0, sizeof(int), s));
+    hipLaunchKernelGGL(finite_check_kernel, dim3(nblk((long long)B * HW * 4)), dim3(256), 0, s, c->x32, (long long)B * HWl * 4, dec->out32,
+                       (long long)B * HW * 4, c->finite_flag);
+  }
   HIP_CHECK(hipEventRecord(c->ev[3], s));
   return LAUNCH_OK();
+}
+
+int dtp_last_stamp_finite(dtp_ctx* ctx, int* finite) {
+  Ctx* c = (Ctx*)ctx;
+  if (!c || !finite) return DTP_ERR_ARG;
+  if (!c->finite_pending) { dtp_set_error("dtp_last_stamp_finite: the last stamp ran without the \"check_finite\" option"); return DTP_ERR_STATE; }
+  HIP_CHECK(hipEventSynchronize(c->ev[3]));
+  int flag = 0;
+  HIP_CHECK(hipMemcpy(&flag, c->finite_flag, sizeof(int), hipMemcpyDeviceToHost));
+  *finite = flag ? 0 : 1;
+  return DTP_OK;
 }
 
 int dtp_last_stamp_times(dtp_ctx* ctx, float ms[3]) {
@@ -443,7 +485,7 @@ int dtp_profile_rows(dtp_ctx* ctx, dtp_prof_row* rows, int max_rows, int* n_rows
   Ctx* c = (Ctx*)ctx;
   if (!c || !rows || !n_rows) return DTP_ERR_ARG;
   HIP_CHECK(hipDeviceSynchronize());
-  dtp_prof_row acc[PK_COUNT] = {};
+  dtp_prof_row acc[PK_COUNT] = {};  // PK_COUNT kinds, see include/dtp.h
   for (int k = 0; k < PK_COUNT; ++k) acc[k].kind = k;
   for (const ProfRec& r : c->prof) {
     float ms = 0.f;
@@ -479,6 +521,7 @@ int dtp_set_option(dtp_ctx* ctx, const char* name, int value) {
   if (!c || !name) return DTP_ERR_ARG;
   if (!strcmp(name, "use_graph")) { c->use_graph = value != 0; return DTP_OK; }
   if (!strcmp(name, "autotune")) { c->autotune = value != 0; return DTP_OK; }
+  if (!strcmp(name, "check_finite")) { c->check_finite = value != 0; return DTP_OK; }
   dtp_set_error("dtp_set_option: unknown option '%s'", name);
   return DTP_ERR_ARG;
 }

@@ -27,8 +27,18 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
         super().__init__()
         if not torch.cuda.is_available():
             raise _lib.DtpError("MI355ConditionalInpainter needs a ROCm GPU (torch.cuda.is_available() is False)")
-        # GEMM (tile, split-K) choices are timed once per shape at build time and persisted here
-        os.environ.setdefault("DTP_TUNE_CACHE", os.path.join(os.environ.get("TMPDIR", "/tmp"), "dtp_tune_cache.txt"))
+        # GEMM (tile, split-K) choices are timed once per shape at build time and persisted in a per-user cache; the table
+        # measured on the build's own MI355X ships with the package as a read-only seed (entries are validated on use)
+        cache_dir = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"),
+                                 "diffusiontexturepainting_amd")
+        try:
+            os.makedirs(cache_dir, mode=0o700, exist_ok=True)
+            os.environ.setdefault("DTP_TUNE_CACHE", os.path.join(cache_dir, "tune_cache.txt"))
+        except OSError:
+            pass  # no writable cache directory: tune in memory only
+        seed_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_seed.txt")
+        if os.path.exists(seed_file):
+            os.environ.setdefault("DTP_TUNE_SEED", seed_file)
         self._lib = _lib.load()
         self._resolution = int(resolution)
         self._index = device if isinstance(device, int) else torch.device(device).index or 0
@@ -47,6 +57,7 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
         self.conditioning = None
         self.image = None
         self.last_times_ms = None
+        self._check_finite = False
 
     # ------------------------------------------------------------------ weights
     def _load(self, nets):
@@ -135,6 +146,8 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
         for t in (canvas, latents, vae_eps, out):
             if t is not None:
                 t.record_stream(self.stream)
+        if self._check_finite and not self.last_stamp_finite():  # debug option: one sync per stamp, like the reference's assert
+            raise _lib.DtpError("stamp produced NaN/inf (check_finite): latents or decoded image are not finite")
         return out
 
     def generate_raw(self, canvas, latents=None, vae_eps=None, **settings):
@@ -178,6 +191,14 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
 
     def set_option(self, name, value):
         check(self._lib.dtp_set_option(self._h, name.encode(), int(value)), "dtp_set_option")
+        if name == "check_finite":
+            self._check_finite = bool(value)
+
+    def last_stamp_finite(self):
+        """Verdict of the post-loop finiteness check of the last stamp (option "check_finite"); blocks on that stamp."""
+        ok = C.c_int()
+        check(self._lib.dtp_last_stamp_finite(self._h, C.byref(ok)), "dtp_last_stamp_finite")
+        return bool(ok.value)
 
     # ------------------------------------------------------------------ engine-level access (inner boundary)
     def unet(self, sample, timestep, encoder_hidden_states):

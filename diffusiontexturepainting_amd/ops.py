@@ -60,7 +60,7 @@ def rowsum(wp, k):
 
 
 def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, out=None, lda=None, lns=None, ln_eps=1e-5, batch=0,
-         sm_valid=0, bias_shared=False, tail=None):
+         sm_valid=0, bias_shared=False, tail=None, row_stats=False, stats_in=None):
     """a f16 [M, >=K] row-major; wp packed weights; returns f16 [M, N] (or [M, N/2] with GEGLU).
     batch > 1: a is [batch*M, K] (problem b = rows b*M..), wp is [batch*Npad, Kpad], bias / lns are [batch*Npad]."""
     lib = _lib.load()
@@ -89,7 +89,16 @@ def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, ou
     if tail is not None:  # second activation matrix: supplies the last tail.shape[1] columns of the contraction
         d.A2, d.lda2, d.Cin2 = tail.data_ptr(), tail.stride(0), tail.shape[1]
         d.K = k + tail.shape[1]
+    st = None
+    if row_stats:  # also return the per-row (sum, sumsq) partials of the fp16 output: f32 [parts, M, 2]
+        st = torch.zeros((n + 63) // 64, a.shape[0], 2, dtype=torch.float32, device=a.device)
+        d.st_out = st.data_ptr()
+        d.flags |= _lib.GF_ROWSTATS
+    if stats_in is not None:  # LayerNorm fold with the producer's partials instead of in-kernel statistics
+        d.st_in, d.st_parts = stats_in.data_ptr(), stats_in.shape[0]
     check(lib.dtp_op_gemm(C.byref(d), _stream()), "gemm")
+    if row_stats:
+        return out, st[: d.st_parts_out]
     return out
 
 
@@ -159,3 +168,14 @@ def softmax_rows(x, scale=1.0):
     y = torch.empty_like(x)
     check(lib.dtp_op_softmax_rows(ptr(x), x.stride(0), ptr(y), y.stride(0), rows, cols, scale, _stream()), "softmax_rows")
     return y
+
+
+def dilate_alpha(canvas, pad):
+    """canvas f32 [B,4,R,R] -> f32 [B,1,R,R]: flat pad x pad dilation of the alpha plane (handler.py:28-29)."""
+    lib = _lib.load()
+    b, _, r, _ = canvas.shape
+    canvas = canvas.contiguous().float()
+    tmp = torch.empty(b, r, r, dtype=torch.float32, device=canvas.device)
+    out = torch.empty(b, 1, r, r, dtype=torch.float32, device=canvas.device)
+    check(lib.dtp_op_dilate(ptr(canvas), ptr(tmp), ptr(out), b, r, int(pad), _stream()), "dilate")
+    return out

@@ -20,9 +20,10 @@
 extern "C" {
 #endif
 
-#define DTP_ABI_VERSION 1
+#define DTP_ABI_VERSION 2
 
-enum { DTP_SUCCESS = 0, DTP_E_ARG = 1, DTP_E_HIP = 2, DTP_E_STATE = 3, DTP_E_MISSING = 4 };
+/* error codes (every entry point returns one; dtp_last_error() has the text) */
+enum { DTP_OK = 0, DTP_ERR_ARG = 1, DTP_ERR_HIP = 2, DTP_ERR_STATE = 3, DTP_ERR_MISSING = 4 };
 
 typedef struct dtp_ctx dtp_ctx;
 typedef void* dtp_stream; /* hipStream_t; NULL = the null stream */
@@ -85,7 +86,10 @@ typedef struct {
  *   latents f32 [B,4,h,w]   initial N(0,1) draw (initialize_latents, sdp:340-346); required
  *   vae_eps f32 [2,B,4,h,w] normal draws of the two VAE encodes (models.py:1335); NULL = mean
  *   out     f32 [B,3,R,R] 0..1 (or u8, see output_u8)
- * Asynchronous on `s`. */
+ * Asynchronous on `s`: the call only enqueues (copies of the inputs, graph replays, kernels with the settings as kernel
+ * arguments) and returns; back-to-back stamps overlap host enqueue with device work.  The caller keeps canvas / latents /
+ * vae_eps / out alive until the stream has consumed them.  The one exception is a CHANGE of `steps` between two calls,
+ * which rebuilds the schedule tables (update_infer_settings, inpaint_pipeline.py:39-50) and waits for the stream once. */
 int dtp_stamp(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const float* latents, const float* vae_eps,
               void* out, int B, dtp_stream s);
 
@@ -107,7 +111,8 @@ int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes);
  * class: kind 0-11 = gemm_kernel<BM,BN,NS> (the implicit-GEMM kernel; id = shape + 4*(NS-2), shape 0..3 =
  * 128x128 / 128x64 / 64x64 / 64x128), 12 = attention_kernel, 13 = GroupNorm (stats+apply or fused),
  * 14 = layernorm, 15 = concat/elementwise, 16 = softmax_rows, 17-20 = conv_halo_kernel<8,16,64> / <8,16,128> / <8,8,64> /
- * <8,8,128> (halo-tiled 3x3 conv), 21-24 = gemm_kernel<256,128,2> / <256,128,3> / <128,256,2> / <128,256,3>.  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
+ * <8,8,128> (halo-tiled 3x3 conv), 21-24 = gemm_kernel<256,128,2> / <256,128,3> / <128,256,2> / <128,256,3>,
+ * 25-26 = gemm_wide_kernel<256,256> / <256,320> (8-wave wide tiles).  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
  * dtp_profile(ctx, 0) switches back to graph replay.  The nvtx/cudaEvent hooks of
  * stable_diffusion_pipeline.py:146-149,486-503 are the reference counterpart. */
 typedef struct { int kind; int launches; double ms; double flops; double bytes; } dtp_prof_row;
@@ -115,8 +120,14 @@ int dtp_profile(dtp_ctx* ctx, int enable);
 int dtp_profile_rows(dtp_ctx* ctx, dtp_prof_row* rows, int max_rows, int* n_rows);
 /* one CSV line per recorded launch: kind,us,tflops,algo_GBps,label */
 int dtp_profile_dump(dtp_ctx* ctx, const char* path);
-/* options: "use_graph" (default 1) */
+/* options: "use_graph" (default 1): replay captured hipGraphs; "autotune" (default 1): time tile x split-K candidates per
+ * contraction shape when a launch program is built; "check_finite" (default 0): after every stamp ONE reduction over the
+ * final latents and the decoded image looks for NaN/inf (the reference asserts `not isnan` after every step with a host
+ * sync each, stable_diffusion_pipeline.py:415) -- read the verdict with dtp_last_stamp_finite. */
 int dtp_set_option(dtp_ctx* ctx, const char* name, int value);
+/* *finite = 1 if the last stamp (run with "check_finite" on) produced only finite values, 0 otherwise.  Blocks until that
+ * stamp has finished; DTP_ERR_STATE if the option was off. */
+int dtp_last_stamp_finite(dtp_ctx* ctx, int* finite);
 
 /* ---------------------------------------------------------------- kernel-level entry points
  * The individual HIP kernels behind the engines, exposed so each can
@@ -134,7 +145,8 @@ typedef struct {
   int flags;         /* DTP_GF_* */
   int tile;          /* -1 = heuristic; gemm_kernel: shape + 4*(stages-2), shape 0:128x128 1:128x64 2:64x64 3:64x128 (MxN),
                         stages 2..4; 12..15 = conv_halo_kernel (8x16|8x8 pixel tile) x (64|128 channels), needs Wcb;
-                        16..19 = gemm_kernel 256x128 (2|3 stages), 128x256 (2|3 stages) */
+                        16..19 = gemm_kernel 256x128 (2|3 stages), 128x256 (2|3 stages);
+                        20 / 21 = gemm_wide_kernel 256x256 / 256x320 (8 waves; unsplit, N % 8 == 0; 21: no GEGLU) */
   int splits;        /* 0 = heuristic; >=1 = forced split-K factor */
   const float* lns;  /* DTP_GF_LNFOLD: row sums of the packed weights (dtp_op_rowsum) */
   float ln_eps;
@@ -146,11 +158,16 @@ typedef struct {
   int64_t a_bs, w_bs, c_bs, r_bs;
   int bias_bs, lns_bs;
   int sm_valid;      /* DTP_GF_SOFTMAX16: softmax over the first sm_valid columns of every aligned group of 16; the rest -> 0 */
+  float* st_out;     /* DTP_GF_ROWSTATS: per-row (sum, sum of squares) of the fp16 output, one partial per N tile: f32
+                        [ceil(N / tile columns)][M][2] (room for ceil(N/64) partials is always enough) */
+  const float* st_in;/* DTP_GF_LNFOLD: row statistics of A handed over by its producer ([st_parts][M][2]); NULL = computed in-kernel */
+  int st_parts;
+  int st_parts_out;  /* written by dtp_op_gemm: number of partials per row the chosen tile emitted into st_out */
 } dtp_gemm_desc;
 enum { DTP_GF_BIAS = 1, DTP_GF_BIAS_M = 2, DTP_GF_RESID = 4, DTP_GF_GEGLU = 8, DTP_GF_GELU = 64, DTP_GF_QUICKGELU = 128,
-       DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512, DTP_GF_LNFOLD = 1024, DTP_GF_SOFTMAX16 = 4096 };
+       DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512, DTP_GF_LNFOLD = 1024, DTP_GF_ROWSTATS = 2048, DTP_GF_SOFTMAX16 = 4096 };
 
-int dtp_op_gemm(const dtp_gemm_desc* d, dtp_stream s);
+int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s);
 /* w f32 [N][K] -> out f16 [rows][ldw] (caller zero-fills out); geglu=1 applies the [a|gate] tile packing */
 int dtp_op_pack_linear(const float* w, void* out, int N, int K, int ldw, int geglu, dtp_stream s);
 /* w f32 [Cout][Cin][3][3] (or 1x1) -> out f16 [rows][ldw], k = tap*Cin_pad + ci (caller zero-fills out) */
@@ -166,6 +183,9 @@ int dtp_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamm
 int dtp_op_attention(const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo, int B, int H,
                      int Sq, int Skv, int D, int64_t qbs, int64_t kbs, int64_t vbs, int64_t obs, float scale, dtp_stream s);
 int dtp_op_softmax_rows(const void* x, int ldx, void* y, int ldy, int rows, int cols, float scale, dtp_stream s);
+/* kornia.morphology.dilation(alpha, ones(pad,pad)) of add_extra_context (handler.py:28-29) as the stamp runs it: canvas f32
+ * [B,4,R,R] (the alpha plane is read), tmp / out f32 [B,R,R]; window rows/cols [i - pad/2, i + pad - pad/2 - 1], clipped */
+int dtp_op_dilate(const float* canvas, float* tmp, float* out, int B, int R, int pad, dtp_stream s);
 
 #ifdef __cplusplus
 }

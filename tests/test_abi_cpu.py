@@ -28,7 +28,7 @@ def test_header_and_binding_agree(lib):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), f"libdtp.so does not export {name}"
-    assert lib.dtp_abi_version() == 1
+    assert lib.dtp_abi_version() == 2
 
 
 def test_ddim_tables_match_reference_fixture(lib, golden_dir):
@@ -43,6 +43,10 @@ def test_ddim_tables_match_reference_fixture(lib, golden_dir):
         assert abs(fin.value - float(g[f"final_alpha_{n}"])) <= 1e-7
     assert lib.dtp_ddim_tables(0, None, None, None) != 0
     assert b"steps" in lib.dtp_last_error()
+    # steps = 1000 would gather alphas_cumprod[1000] (IndexError in the reference): rejected, 999 is the largest schedule
+    assert lib.dtp_ddim_tables(1000, None, None, None) != 0
+    ts = (C.c_int64 * 999)()
+    assert lib.dtp_ddim_tables(999, ts, None, None) == 0 and max(ts) == 999 and min(ts) == 1
 
 
 def test_missing_library_is_loud(monkeypatch):

@@ -136,7 +136,7 @@ def test_stamp_u8_and_internal_noise(env):
     assert r1.shape == (1, 3, R, R) and not torch.equal(r1, r2)
 
 
-@pytest.mark.parametrize("shape", [(3, 128, 128), (3, 200, 150), (3, 224, 224), (3, 96, 160)])
+@pytest.mark.parametrize("shape", [(3, 128, 128), (3, 200, 150), (3, 224, 224), (3, 96, 160), (3, 133, 128), (3, 128, 137)])  # the last two: (H-m)/2 = x.5 -> round-half-even crop offsets
 def test_set_brush_vs_oracle(env, shape):
     """set_brush = crop_resize_square + ConditionPatchEncoder.encode_image (trt_model.py:79-88)."""
     from oracle import image_encoder as IE, pipeline

@@ -107,3 +107,20 @@ def test_config4_256_8steps_matches_cpu_oracle(weights):
     err = (got.cpu() - ref).abs().max().item()
     print("256^2 / 8 steps: max abs pixel error", err, "stage ms", m.stage_times_ms())
     assert err <= 1e-2 and m.stamp_info()["unet_evals"] == 7
+
+
+def test_256_20steps_matches_cpu_oracle(weights):
+    """The reference server's own operating point (run.py:30: resolution 256; Kit default 20 steps): 19 UNet evaluations of
+    accumulated fp16 error against the fp32 oracle (about a minute of host time)."""
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    from oracle import pipeline
+    m = MI355ConditionalInpainter(256, device=0, weights=weights[0], max_batch=1)
+    canvas, brush, cond, uncond, lat, eps = _inputs(1, 256, 500)
+    st = dict(steps=20, context_pad=150, tg_steps=5, cfg_weight=2.0, tg_weight=1.0)  # tg cut-off mid-loop: both programs run
+    m.set_conditioning(cond, uncond, brush)
+    got = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
+    torch.cuda.synchronize()
+    ref = pipeline.generate_raw(weights[1], brush, cond, uncond, canvas, lat, eps, **st)
+    err = (got.cpu() - ref).abs().max().item()
+    print("256^2 / 20 steps: max abs pixel error", err, "stage ms", m.stage_times_ms())
+    assert err <= 1e-2 and m.stamp_info()["unet_evals"] == 19

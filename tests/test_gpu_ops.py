@@ -36,7 +36,7 @@ def close(got, ref, tol=2e-3):
 
 
 @pytest.mark.parametrize("m,n,k", [(300, 320, 320), (4096, 640, 1280), (192, 1280, 2560), (77, 768, 768), (14, 1280, 768)])
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19])  # shape + 4 * (stages - 2); 16.. = 256-wide tiles
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 20, 21])  # shape + 4 * (stages - 2); 16.. = 256-wide tiles; 20 / 21 = 8-wave wide tiles
 def test_gemm_dense(ops, m, n, k, tile):
     a, w = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5)
     bias = torch.randn(n, generator=torch.Generator().manual_seed(3))
@@ -70,8 +70,8 @@ def test_gemm_asymmetric_identity(ops):
     close(got, w.float().t(), tol=1e-6)
 
 
-@pytest.mark.parametrize("m,c", [(512, 320), (100, 1280)])
-def test_gemm_geglu(ops, m, c):
+@pytest.mark.parametrize("m,c,tile", [(512, 320, -1), (100, 1280, -1), (700, 320, 20), (300, 640, 20)])
+def test_gemm_geglu(ops, m, c, tile):
     a, w = rnd(m, c, seed=8), rnd(8 * c, c, seed=9, scale=c ** -0.5)
     bias = torch.randn(8 * c, generator=torch.Generator().manual_seed(10)) * 0.1
     h = F.linear(a.float(), w.float(), bias)
@@ -86,12 +86,13 @@ def test_gemm_geglu(ops, m, c):
     bp = torch.empty_like(bias)
     bp[perm] = bias
     from diffusiontexturepainting_amd._lib import GF_BIAS, GF_GEGLU
-    got = ops.gemm(a.cuda(), wp, 8 * c, c, bias=bp.cuda(), flags=GF_GEGLU | GF_BIAS)
+    got = ops.gemm(a.cuda(), wp, 8 * c, c, bias=bp.cuda(), flags=GF_GEGLU | GF_BIAS, tile=tile)
     close(got, ref)
 
 
 @pytest.mark.parametrize("m,c,n,tile,geglu", [(300, 320, 960, -1, False), (100, 1280, 1280, 6, False), (513, 640, 5120, -1, True),
-                                             (64, 768, 768, 3, False), (513, 640, 5120, 17, True), (300, 320, 960, 18, False)])
+                                             (64, 768, 768, 3, False), (513, 640, 5120, 17, True), (300, 320, 960, 18, False),
+                                             (513, 640, 5120, 20, True), (300, 320, 960, 21, False), (700, 320, 960, 20, False)])
 def test_gemm_layernorm_fold(ops, m, c, n, tile, geglu):
     """LN(x) W^T + b computed from the RAW x: W carries gamma, bias carries W.beta, statistics in-kernel."""
     from diffusiontexturepainting_amd._lib import GF_BIAS, GF_GEGLU
@@ -153,7 +154,8 @@ def test_gemm_batched_residual(ops):
     close(got, ref)
 
 
-@pytest.mark.parametrize("m,k1,k2,n,tile,splits", [(300, 1280, 320, 320, -1, 0), (130, 256, 64, 192, 2, 3), (768, 640, 128, 640, 17, 1), (64, 128, 128, 128, 5, 2)])
+@pytest.mark.parametrize("m,k1,k2,n,tile,splits", [(300, 1280, 320, 320, -1, 0), (130, 256, 64, 192, 2, 3), (768, 640, 128, 640, 17, 1), (64, 128, 128, 128, 5, 2),
+                                                   (768, 640, 128, 640, 21, 1), (600, 1280, 320, 320, 20, 1)])
 def test_gemm_two_activation_matrices(ops, m, k1, k2, n, tile, splits):
     """[f | r] . [W1 | W2]^T with f and r in separate buffers: how ff.net.2 (+residual) and proj_out run as one GEMM."""
     f, r = rnd(m, k1, seed=30), rnd(m, k2, seed=31)
@@ -165,15 +167,22 @@ def test_gemm_two_activation_matrices(ops, m, k1, k2, n, tile, splits):
     close(got, ref)
 
 
-def test_gemm_epilogues(ops):
-    from diffusiontexturepainting_amd._lib import GF_BIAS_M, GF_GELU, GF_QUICKGELU
+@pytest.mark.parametrize("tile", [-1, 20, 21])
+def test_gemm_epilogues(ops, tile):
+    from diffusiontexturepainting_amd._lib import GF_BIAS_M, GF_GELU, GF_QUICKGELU, GF_SILU
     m, n, k = 130, 256, 192
     a, w = rnd(m, k, seed=11), rnd(n, k, seed=12, scale=k ** -0.5)
     bias = torch.randn(n, generator=torch.Generator().manual_seed(13))
     wp = ops.pack_linear(w.float().cuda())
     lin = F.linear(a.float(), w.float(), bias)
-    close(ops.gemm(a.cuda(), wp, n, k, bias=bias.cuda(), flags=GF_GELU), F.gelu(lin))
-    close(ops.gemm(a.cuda(), wp, n, k, bias=bias.cuda(), flags=GF_QUICKGELU), lin * torch.sigmoid(1.702 * lin))
+    close(ops.gemm(a.cuda(), wp, n, k, bias=bias.cuda(), flags=GF_GELU, tile=tile), F.gelu(lin))
+    close(ops.gemm(a.cuda(), wp, n, k, bias=bias.cuda(), flags=GF_QUICKGELU, tile=tile), lin * torch.sigmoid(1.702 * lin))
+    close(ops.gemm(a.cuda(), wp, n, k, bias=bias.cuda(), flags=GF_SILU, tile=tile), F.silu(lin))
+    if tile >= 20:
+        from diffusiontexturepainting_amd._lib import DtpError
+        with pytest.raises(DtpError):  # per-row bias is not an epilogue of the wide tiles: loud, not silent
+            ops.gemm(a.cuda(), wp, n, k, bias=torch.zeros(m).cuda(), flags=GF_BIAS_M, tile=tile)
+        return
     # operand-swapped call: out[n'][m'] = W x^T + bias[n'] (how V^T is produced for the VAE attention)
     bm = torch.randn(m, generator=torch.Generator().manual_seed(14))
     got = ops.gemm(a.cuda(), wp, n, k, bias=bm.cuda(), flags=GF_BIAS_M)
@@ -195,10 +204,12 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [-1, 5, 8, 10, 16, 19])
+@pytest.mark.parametrize("tile", [-1, 5, 8, 10, 16, 19, 20, 21])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3x3(ops, case, tile):
     b, h, w, cin, cout, stride, pad, ups, out_hw = case
+    if tile >= 20 and cout % 8:
+        pytest.skip("the wide tiles need N % 8 == 0")
     x = rnd(b, h, w, cin, seed=20)
     wt = rnd(cout, cin, 3, 3, seed=21, scale=(9 * cin) ** -0.5)
     bias = torch.randn(cout, generator=torch.Generator().manual_seed(22))
@@ -219,7 +230,8 @@ def test_conv3x3(ops, case, tile):
 
 
 @pytest.mark.parametrize("b,h,cin,cin2,cout,tile,splits", [(2, 16, 64, 128, 64, -1, 0), (3, 8, 320, 640, 320, 5, 0), (1, 8, 128, 64, 256, 8, 3),
-                                                           (3, 16, 320, 640, 320, 17, 2), (1, 16, 128, 64, 256, 18, 0)])
+                                                           (3, 16, 320, 640, 320, 17, 2), (1, 16, 128, 64, 256, 18, 0),
+                                                           (3, 16, 320, 640, 320, 21, 1), (1, 16, 128, 64, 256, 20, 1)])
 def test_conv3x3_fused_shortcut(ops, b, h, cin, cin2, cout, tile, splits):
     """ResBlock tail as ONE contraction: conv3x3(t) + conv1x1(x) + biases = [im2col(t) | x] . [W3 | W1]^T."""
     t, x = rnd(b, h, h, cin, seed=24), rnd(b, h, h, cin2, seed=25)
@@ -344,3 +356,40 @@ def test_softmax_rows(ops):
     x = rnd(300, 4096, seed=80) * 3
     ref = torch.softmax(x.float() * 0.21, dim=-1)
     close(ops.softmax_rows(x.cuda(), 0.21), ref, tol=1e-3)
+
+
+@pytest.mark.parametrize("m,n,k,tile", [(300, 320, 320, -1), (700, 640, 640, 0), (700, 640, 640, 20), (130, 1280, 320, 2), (513, 320, 1280, 20)])
+def test_gemm_row_statistics_feed_the_layernorm_fold(ops, m, n, k, tile):
+    """Producer GEMM emits per-row (sum, sumsq) partials of its fp16 output (one per N tile); a LayerNorm-folded consumer
+    that takes them must equal the consumer that computes the statistics itself -- and the fp32 LayerNorm reference."""
+    a, w = rnd(m, k, seed=100), rnd(n, k, seed=101, scale=k ** -0.5)
+    bias = torch.randn(n, generator=torch.Generator().manual_seed(102))
+    r = rnd(m, n, seed=103)
+    y, st = ops.gemm(a.cuda(), ops.pack_linear(w.float().cuda()), n, k, bias=bias.cuda(), resid=r.cuda(), tile=tile, row_stats=True)
+    yf = y.float().cpu()
+    tot = st.sum(dim=0).cpu()
+    assert torch.allclose(tot[:, 0], yf.sum(dim=1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(tot[:, 1], (yf * yf).sum(dim=1), rtol=1e-4, atol=1e-2)
+    n2 = 384
+    w2 = rnd(n2, n, seed=104, scale=n ** -0.5).float()
+    g = torch.Generator().manual_seed(105)
+    gamma, beta = 1 + 0.2 * torch.randn(n, generator=g), 0.2 * torch.randn(n, generator=g)
+    ref = F.linear(F.layer_norm(yf, (n,), gamma, beta, 1e-5), w2)
+    wp2 = ops.pack_linear((w2 * gamma[None]).cuda())
+    lns = ops.rowsum(wp2, n)
+    b2 = (w2 @ beta).cuda()
+    for t2 in (-1, 20):
+        own = ops.gemm(y, wp2, n2, n, bias=b2, lns=lns, tile=t2)
+        fed = ops.gemm(y, wp2, n2, n, bias=b2, lns=lns, tile=t2, stats_in=st)
+        close(own, ref, tol=3e-3)
+        close(fed, ref, tol=3e-3)
+
+
+def test_gemm_wide_large_asymmetric(ops):
+    """Several 256-row tiles, ragged M and N tails, non-square: catches tile / wave-grid index mix-ups of the 8-wave kernels."""
+    for tile, (m, n, k) in ((20, (1000, 776, 448)), (21, (1000, 968, 448)), (21, (2304, 320, 2880))):
+        a, w = rnd(m, k, seed=110), rnd(n, k, seed=111, scale=k ** -0.5)
+        bias = torch.randn(n, generator=torch.Generator().manual_seed(112))
+        ref = F.linear(a.float(), w.float(), bias)
+        got = ops.gemm(a.cuda(), ops.pack_linear(w.float().cuda()), n, k, bias=bias.cuda(), tile=tile)
+        close(got, ref)

@@ -1,0 +1,268 @@
+"""Round-2 parity cases on the GPU (all through the C ABI, checked against the fp32 CPU oracle):
+
+  * stamps with B = 3 and B = 8 at R = 64 against the oracle (the B > 2 programs were only compared with themselves before);
+  * two (B, NB) splits that share one UNet batch N = 6 on ONE context (K/V cache validity);
+  * destroy -> create at another resolution in one process (stamp / brush staging lives in the context);
+  * direct dilation cases (odd / even / pad > R), attention at the level-0 shape S = 4096 / d = 40 and the VAE mid-block
+    path S = 4096 / d = 512 (GEMM -> row softmax -> GEMM);
+  * handler flow bytes -> bytes exactly as trt_inference/handler.py:91-123 does it, including the preview path;
+  * an outlier-statistics stress case (a few 50x channels, LayerNorm inputs with |mean| >> std) and the finiteness guard;
+  * dtp_stamp does not block the host.
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+R = 64
+
+
+@pytest.fixture(scope="module")
+def sd():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffusiontexturepainting_amd import weights as W
+    return dict(unet=W.synthetic_unet(11), lora=W.synthetic_lora(11), vae=W.synthetic_vae(11), clip=W.synthetic_clip(11),
+                penc=W.synthetic_patch_encoder(11))
+
+
+@pytest.fixture(scope="module")
+def env(sd):
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    from oracle import nets
+    model = MI355ConditionalInpainter(R, device=0, weights=sd, max_batch=8)
+    return dict(model=model, nets=dict(unet=nets.merge_lora(sd["unet"], sd["lora"]), vae=sd["vae"]))
+
+
+def _inputs(b, res, seed):
+    from diffusiontexturepainting_amd import synthetic
+    canvas, brush, lat, eps = synthetic.make_stamp_batch(b, res, seed)
+    cond, uncond = synthetic.make_conditioning(seed + 1)
+    return canvas, brush, cond, uncond, lat, eps
+
+
+@pytest.mark.parametrize("b,steps,tg_steps,tg", [(3, 4, 4, 1.0), (8, 3, 3, 1.0), (5, 4, 2, 1.5)])
+def test_batched_stamps_vs_oracle(env, b, steps, tg_steps, tg):
+    from oracle import pipeline
+    canvas, brush, cond, uncond, lat, eps = _inputs(b, R, 500 + b)
+    st = dict(steps=steps, context_pad=9, tg_steps=tg_steps, cfg_weight=2.0, tg_weight=tg)
+    m = env["model"]
+    m.set_conditioning(cond, uncond, brush)
+    got = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st).cpu()
+    ref = pipeline.generate_raw(env["nets"], brush, cond, uncond, canvas, lat, eps, **st)
+    err = (got - ref).abs().max().item()
+    print(f"B={b} stamp vs oracle: max abs err {err:.2e}")
+    assert err <= 1e-2
+
+
+def test_mixed_splits_sharing_one_unet_batch(env):
+    """B=2 with texture guidance (3 branches) and B=3 without (2 branches) both run the N=6 UNet program: the context
+    layout [uncond x B | cond x (NB-1)B] differs, so the cached K/V must be rebuilt when the split changes."""
+    from oracle import pipeline
+    m = env["model"]
+    c2 = _inputs(2, R, 610)
+    c3 = _inputs(3, R, 620)
+    m.set_conditioning(c2[2], c2[3], c2[1])
+    for (canvas, brush, cond, uncond, lat, eps), tg in ((c2, 1.0), (c3, 0.0), (c2, 1.0)):
+        st = dict(steps=3, context_pad=7, tg_steps=3, cfg_weight=3.0, tg_weight=tg)
+        got = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st).cpu()
+        ref = pipeline.generate_raw(env["nets"], c2[1], c2[2], c2[3], canvas, lat, eps, **st)
+        err = (got - ref).abs().max().item()
+        print(f"B={canvas.shape[0]} tg={tg}: {err:.2e}")
+        assert err <= 1e-2
+
+
+def test_destroy_then_create_at_another_resolution(sd):
+    """The per-batch stamp staging and the brush-encoder buffers die with their context (they used to sit in process-global
+    maps keyed by the context ADDRESS, which the allocator hands straight back to the next context)."""
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    from oracle import nets, pipeline
+    ref_nets = dict(unet=nets.merge_lora(sd["unet"], sd["lora"]), vae=sd["vae"])
+    for res in (64, 128, 64):
+        m = MI355ConditionalInpainter(res, device=0, weights=sd, max_batch=1)
+        canvas, brush, cond, uncond, lat, eps = _inputs(1, res, 700 + res)
+        m.set_brush(torch.rand(3, res + 5, res, generator=torch.Generator().manual_seed(res)))  # exercises the brush buffers
+        m.set_conditioning(cond, uncond, brush)
+        st = dict(steps=3, context_pad=5, tg_steps=3, cfg_weight=2.0, tg_weight=1.0)
+        got = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st).cpu()
+        ref = pipeline.generate_raw(ref_nets, brush, cond, uncond, canvas, lat, eps, **st)
+        assert (got - ref).abs().max().item() <= 1e-2
+        m._lib.dtp_destroy(m._h)
+        m._h = None
+
+
+@pytest.mark.parametrize("res", [64, 128])
+@pytest.mark.parametrize("pad", [1, 2, 5, 20, 149, 150, 151])
+def test_dilation_direct(res, pad):
+    from diffusiontexturepainting_amd import ops
+    from oracle import pipeline
+    g = torch.Generator().manual_seed(res * 1000 + pad)
+    canvas = torch.rand(2, 4, res, res, generator=g)
+    canvas[:, 3] = (torch.rand(2, res, res, generator=g) > 0.97).float() * torch.rand(2, res, res, generator=g)  # not binarised
+    ref = pipeline.dilate_flat(canvas[:, 3:], pad)
+    got = ops.dilate_alpha(canvas.cuda(), pad).cpu()
+    assert torch.equal(got, ref)  # max of the same fp32 values: bit-exact
+
+
+def test_attention_level0_shape():
+    """UNet level-0 self-attention as the 512^2 stamp runs it: S = 4096, 8 heads of d = 40, q/k/v views of one buffer."""
+    from diffusiontexturepainting_amd import ops
+    b, s, heads, d = 1, 4096, 8, 40
+    c = heads * d
+    g = torch.Generator().manual_seed(90)
+    qkv = (torch.randn(b, s, 3 * c, generator=g) * 1.2).half()
+    q, k, v = (qkv[..., i * c:(i + 1) * c].float().view(b, s, heads, d).transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(b, s, c)
+    x = qkv.cuda()
+    got = ops.attention(x[..., :c], x[..., c:2 * c], x[..., 2 * c:], heads).float().cpu()
+    err = (got - ref).abs().max().item()
+    assert torch.isfinite(got).all() and err <= 3e-3 * ref.abs().max().item() + 3e-3, err
+
+
+def test_vae_mid_attention_path():
+    """AutoencoderKL mid-block attention at 512^2: one head of d = 512 over S = 4096 tokens, run as GEMM (Q K^T) -> row
+    softmax -> GEMM (P V) exactly like csrc/vae.hip::vae_attention does."""
+    from diffusiontexturepainting_amd import ops
+    s, c = 4096, 512
+    g = torch.Generator().manual_seed(91)
+    q, k, v = ((torch.randn(s, c, generator=g) * 0.8).half() for _ in range(3))
+    ref = torch.softmax(q.float() @ k.float().t() * c ** -0.5, dim=-1) @ v.float()
+    scores = ops.gemm(q.cuda(), k.cuda(), s, c)              # K rows act as the "weights": [S][C], K contiguous
+    p = ops.softmax_rows(scores, c ** -0.5)
+    got = ops.gemm(p, v.t().contiguous().cuda(), c, s).float().cpu()
+    err = (got - ref).abs().max().item()
+    assert torch.isfinite(got).all() and err <= 3e-3 * ref.abs().max().item() + 3e-3, err
+
+
+def test_handler_flow_bytes_to_bytes(env, sd):
+    """trt_inference/handler.py:91-123 step by step on wire bytes: NEW_BRUSH_IMAGE -> set_brush -> preview stamp over
+    cat([model.image, preview_mask]) -> RETURN_PREVIEW; NEW_STAMP -> np_to_torch -> generate -> torch_to_np -> RETURN_STAMP."""
+    from diffusiontexturepainting_amd import server_io as sio
+    from oracle import image_encoder as IE, pipeline
+    m = env["model"]
+    rng = np.random.default_rng(5)
+    hdr = sio.encode_inference_settings(steps=3, width=R, context_pad=9, cfg_weight=2.0, tg_weight=1.0, tg_steps=3)
+
+    def handle(raw, noise):
+        """the handler body, verbatim in structure; `noise` pins the generator draws so the oracle sees the same ones"""
+        meta, settings, off = sio.decode_request_metadata(raw)
+        if meta["type"] == sio.RequestType.NEW_BRUSH_IMAGE.value:
+            req = sio.decode_new_brush_image_request(raw, off)
+            m.set_brush(pipeline.np_to_torch(req["image"]))
+            mask = pipeline.preview_mask(m.resolution()).to(m.device())
+            context = torch.cat([m.image, mask], dim=1)
+            result = m.generate(context, latents=noise[0], vae_eps=noise[1], **settings).cpu()
+            return sio.encode_generated_response(sio.RequestType.RETURN_PREVIEW, pipeline.torch_to_np(result[0, ...]))
+        assert meta["type"] == sio.RequestType.NEW_STAMP.value
+        context = pipeline.np_to_torch(sio.binary_to_image(raw, off)).unsqueeze(0).to(m.device())
+        result = m.generate(context, latents=noise[0], vae_eps=noise[1], **settings).cpu()
+        return sio.encode_generated_response(sio.RequestType.RETURN_STAMP, pipeline.torch_to_np(result[0, ...]))
+
+    def oracle_reply(kind, canvas, brush_img, noise):
+        emb, unc = IE.encode_image(sd["clip"], sd["penc"], brush_img)
+        raw = pipeline.generate_raw(env["nets"], brush_img, emb, unc, canvas, noise[0], noise[1], steps=3, context_pad=9,
+                                    tg_steps=3, cfg_weight=2.0, tg_weight=1.0)
+        return kind, pipeline.torch_to_np(pipeline.composite(canvas, raw)[0])
+
+    h = R // 8
+    g = torch.Generator().manual_seed(77)
+    noise = (torch.randn(1, 4, h, h, generator=g), torch.randn(2, 1, 4, h, h, generator=g))
+    # ---- new brush (RGBA on the wire; the handler keeps RGB) -> preview
+    brush_u8 = rng.integers(0, 256, size=(R + 10, R, 4), dtype=np.uint8)
+    msg = sio.encode_request_type(sio.RequestType.NEW_BRUSH_IMAGE) + hdr + sio.encode_new_brush_image_request(brush_u8)
+    reply = sio.decode_response(handle(msg, noise))
+    brush_img = pipeline.crop_resize_square(pipeline.np_to_torch(brush_u8[..., :3]), R).unsqueeze(0)
+    canvas = torch.cat([brush_img, pipeline.preview_mask(R)], dim=1)
+    kind, want = oracle_reply(sio.RequestType.RETURN_PREVIEW.value, canvas, brush_img, noise)
+    assert reply["type"] == kind and reply["image"].shape == (R, R, 3)
+    assert np.abs(reply["image"].astype(int) - want.astype(int)).max() <= 3  # 1e-2 of 255, +-1 for the truncation
+    known = canvas[0, 3].numpy() == 1
+    assert np.array_equal(reply["image"][known], pipeline.torch_to_np(brush_img[0])[known])  # painted pixels bit-exact
+    # ---- stamp
+    canvas_u8 = rng.integers(0, 256, size=(R, R, 4), dtype=np.uint8)
+    canvas_u8[..., 3] = np.where(rng.random((R, R)) > 0.5, 255, 0)
+    msg = sio.encode_request_type(sio.RequestType.NEW_STAMP) + hdr + sio.image_to_binary(canvas_u8)
+    reply = sio.decode_response(handle(msg, noise))
+    kind, want = oracle_reply(sio.RequestType.RETURN_STAMP.value, pipeline.np_to_torch(canvas_u8).unsqueeze(0), brush_img, noise)
+    assert reply["type"] == kind
+    assert np.abs(reply["image"].astype(int) - want.astype(int)).max() <= 3
+
+
+def test_outlier_statistics_stress(sd):
+    """Real SD-1.5 activations carry outlier channels and LayerNorm inputs whose mean is far from zero; the synthetic weights
+    are O(1) everywhere.  Rescale: two conv_in output channels x50, +8 on every proj_in bias (|mean| ~ 8 std into LN1/LN2/LN3,
+    which are folded into their consumer GEMMs from E[x^2] - mean^2).  The HIP UNet must stay within the engine tolerance."""
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    from oracle import nets
+    u = {k: v.clone() for k, v in sd["unet"].items()}
+    u["conv_in.weight"][[5, 77]] *= 50.0
+    for k in u:
+        if k.endswith("proj_in.bias"):
+            u[k] += 8.0
+    m = MI355ConditionalInpainter(R, device=0, weights=dict(unet=u, lora=sd["lora"], vae=sd["vae"]), max_batch=1)
+    merged = nets.merge_lora(u, sd["lora"])
+    g = torch.Generator().manual_seed(3)
+    sample = torch.randn(3, 9, R // 8, R // 8, generator=g)
+    ctx = torch.randn(3, 14, 768, generator=g).half()
+    ref, trace = nets.unet_forward(merged, sample, torch.tensor(501.0), ctx.float(), return_trace=True)
+    got = m.unet(sample, 501.0, ctx).cpu()
+    rel = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(f"outlier stress: rel err {rel:.2e}, max |activation| in the oracle trace "
+          f"{max(float(t.abs().max()) for t in trace.values()) if isinstance(trace, dict) else float('nan'):.1f}")
+    assert torch.isfinite(got).all() and rel < 3e-2
+
+
+def test_check_finite_option(env):
+    from diffusiontexturepainting_amd._lib import DtpError
+    m = env["model"]
+    canvas, brush, cond, uncond, lat, eps = _inputs(1, R, 810)
+    m.set_conditioning(cond, uncond, brush)
+    st = dict(steps=3, context_pad=5, tg_steps=3, cfg_weight=2.0, tg_weight=1.0)
+    with pytest.raises(DtpError):
+        m.last_stamp_finite()  # option off: no verdict to read
+    m.set_option("check_finite", 1)
+    try:
+        out = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
+        assert m.last_stamp_finite() and torch.isfinite(out).all()
+        bad = lat.clone()
+        bad[0, 1, 2, 3] = float("nan")
+        with pytest.raises(DtpError, match="NaN/inf"):
+            m.generate_raw(canvas, latents=bad, vae_eps=eps, **st)
+    finally:
+        m.set_option("check_finite", 0)
+    again = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
+    assert torch.equal(again, out)
+
+
+def test_stamp_enqueue_does_not_block_the_host():
+    """dtp_stamp only enqueues (include/dtp.h): two back-to-back stamps return to the host long before the device is done."""
+    from diffusiontexturepainting_amd import weights as W
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    res = 256
+    m = MI355ConditionalInpainter(res, device=0, weights=dict(unet=W.synthetic_unet(2), lora=W.synthetic_lora(2), vae=W.synthetic_vae(2)),
+                                  max_batch=1)
+    canvas, brush, cond, uncond, lat, eps = _inputs(1, res, 900)
+    m.set_conditioning(cond, uncond, brush)
+    st = dict(steps=20, context_pad=150, tg_steps=20, cfg_weight=2.0, tg_weight=1.0)
+    canvas, lat, eps = canvas.cuda(), lat.cuda(), eps.cuda()
+    for _ in range(2):  # capture + warm
+        m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    a = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
+    b = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    print(f"host enqueue of 2 stamps {t_host * 1e3:.1f} ms, device done after {t_all * 1e3:.1f} ms")
+    assert torch.equal(a, b)
+    assert t_host < 0.5 * t_all
+    # changing cfg between two in-flight stamps takes effect per stamp (kernel-argument header, no shared staging buffer)
+    c1 = m.generate_raw(canvas, latents=lat, vae_eps=eps, **{**st, "cfg_weight": 5.0})
+    c2 = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
+    torch.cuda.synchronize()
+    assert torch.equal(c2, a) and not torch.equal(c1, a)
