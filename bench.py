@@ -51,15 +51,78 @@ def cpu_baseline(res, ddim_steps, weights, budget_note):
                       f"extrapolated to {ddim_steps - 1} evals + 2 encodes + 1 decode = {stamp_s:.1f}s/stamp; {budget_note}"}
 
 
+def kernel_source_hash():
+    """sha1 over the HIP sources + headers the library was built from: ties a PMC summary to the build it was collected on."""
+    import hashlib
+    csrc = os.path.join(ROOT, "diffusiontexturepainting_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(batch):
     """HBM bytes per launch of the implicit-GEMM kernel class from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
-    (profiles/, collected by tools/pmc_unet.sh on eager UNet evaluations: counters cannot be read from inside this process)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_unet_traffic.json")
+    (profiles/, collected by tools/pmc_unet.sh on eager UNet evaluations: counters cannot be read from inside this process).
+    The summary carries the kernel-source hash it was collected on; if the running build differs, traffic is reported as null
+    (a stale number is worse than none)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_unet_traffic.json")
     if batch != 1 or not os.path.exists(path):
         return {"traffic": None}
     t = json.load(open(path))
+    if t.get("kernel_source_hash") != kernel_source_hash():
+        return {"traffic": None, "traffic_note": f"profiles/r02_pmc_unet_traffic.json was collected on build {t.get('kernel_source_hash')}, "
+                                                 f"this build is {kernel_source_hash()}: not reported"}
     return {"traffic": t["traffic_bytes_per_launch"], "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
-            "traffic_source": "profiles/r01_pmc_unet_traffic.json"}
+            "traffic_source": "profiles/r02_pmc_unet_traffic.json", "traffic_kernel_source_hash": t["kernel_source_hash"]}
+
+
+def time_stamps(model, batch, res, ddim_steps, n, warm, seed):
+    """ms per stamp batch (inputs resident, torch.cuda.synchronize on both sides) of `n` timed batches after `warm` untimed ones."""
+    from diffusiontexturepainting_amd import synthetic
+    canvas, brush, lat, eps = synthetic.make_stamp_batch(batch, res, seed=seed)
+    cond, uncond = synthetic.make_conditioning(7)
+    model.set_conditioning(cond, uncond, brush)
+    dev = model.device()
+    canvas, lat, eps = canvas.to(dev), lat.to(dev), eps.to(dev)
+    st = dict(steps=ddim_steps, context_pad=150, tg_steps=ddim_steps, cfg_weight=2.0, tg_weight=1.0)
+    for _ in range(warm):
+        model._stamp(canvas, st, composite=True, latents=lat, vae_eps=eps, output_u8=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        model._stamp(canvas, st, composite=True, latents=lat, vae_eps=eps, output_u8=True)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def extra_measurements(model512, sd):
+    """Driver-witnessed numbers for the other BASELINE configurations, in the same JSON line: configs[2] (8 x 512^2, 20 steps,
+    throughput mode), the reference server's own operating point (256^2, 20 steps; run.py:30), the configs[4] workload in fp16
+    (256^2, 8 steps), and the pixel error of a small stamp against the fp32 CPU oracle."""
+    from diffusiontexturepainting_amd import synthetic
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    from oracle import nets, pipeline
+    out = {}
+    ms8 = time_stamps(model512, 8, 512, 20, n=3, warm=1, seed=2000)
+    out["configs[2]_batch8_512px_20steps"] = {"stamps_per_s": 8e3 / ms8, "ms_per_batch": ms8, "timed_batches": 3, "dtype": "f16"}
+    m256 = MI355ConditionalInpainter(256, device=model512._index, weights=sd, max_batch=1)
+    ms = time_stamps(m256, 1, 256, 20, n=5, warm=2, seed=2100)
+    out["reference_operating_point_256px_20steps"] = {"stamps_per_s": 1e3 / ms, "ms_per_stamp": ms, "timed_stamps": 5, "dtype": "f16"}
+    ms = time_stamps(m256, 1, 256, 8, n=5, warm=2, seed=2200)
+    out["configs[4]_workload_256px_8steps_in_f16"] = {"stamps_per_s": 1e3 / ms, "ms_per_stamp": ms, "timed_stamps": 5, "dtype": "f16"}
+    del m256
+    m64 = MI355ConditionalInpainter(64, device=model512._index, weights=sd, max_batch=2)
+    canvas, brush, lat, eps = synthetic.make_stamp_batch(2, 64, seed=2300)
+    cond, uncond = synthetic.make_conditioning(8)
+    m64.set_conditioning(cond, uncond, brush)
+    st = dict(steps=4, context_pad=9, tg_steps=4, cfg_weight=2.0, tg_weight=1.0)
+    got = m64.generate_raw(canvas, latents=lat, vae_eps=eps, **st).cpu()
+    ref = pipeline.generate_raw(dict(unet=nets.merge_lora(sd["unet"], sd["lora"]), vae=sd["vae"]), brush, cond, uncond, canvas, lat, eps, **st)
+    out["pixel_max_abs_err_vs_cpu_oracle"] = {"value": (got - ref).abs().max().item(), "gate": 1e-2,
+                                              "case": "2 x 64x64 stamps, 4 DDIM steps, same weights / noise on both sides"}
+    return out
 
 
 def main():
@@ -72,6 +135,7 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra configurations (batch 8, 256 px, oracle pixel error)")
     ap.add_argument("--dump-launches", default="", help="CSV with one line per profiled kernel launch")
     a = ap.parse_args()
 
@@ -89,7 +153,7 @@ def main():
     dev = torch.device("cuda", local)
 
     sd = dict(unet=W.synthetic_unet(), lora=W.synthetic_lora(), vae=W.synthetic_vae())
-    model = MI355ConditionalInpainter(a.res, device=local, weights=sd, max_batch=a.batch)
+    model = MI355ConditionalInpainter(a.res, device=local, weights=sd, max_batch=max(a.batch, 8))
     settings = dict(steps=a.ddim_steps, context_pad=150, tg_steps=a.ddim_steps, cfg_weight=2.0, tg_weight=1.0)  # Kit defaults
     canvas, brush, lat, eps = synthetic.make_stamp_batch(a.batch, a.res, seed=1000 + rank)
     cond, uncond = synthetic.make_conditioning(7)
@@ -154,15 +218,23 @@ def main():
     if not a.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(a.res, a.ddim_steps, sd, "bounded sample, not a full stamp")
 
+    extras = None
+    if not a.no_extras and rank == 0 and world == 1 and (a.batch, a.res, a.ddim_steps) == (1, 512, 20):
+        extras = extra_measurements(model, sd)
+
     if rank == 0:
         lat_sorted = sorted(lat_ms)
+        cfg_idx = {(1, 512, 20): 1, (8, 512, 20): 2, (1, 256, 8): 4}.get((a.batch, a.res, a.ddim_steps))
+        cfg_name = f"BASELINE.json configs[{cfg_idx}]" if cfg_idx is not None else "not a BASELINE.json configuration"
+        if cfg_idx == 4:
+            cfg_name += " workload in fp16 (the fp8 variant is selected with DTP_FP8=1)"
         line = {
             "metric": "512x512 inpaint stamps/sec @20 DDIM steps" if (a.res, a.ddim_steps) == (512, 20) else
                       f"{a.res}x{a.res} inpaint stamps/sec @{a.ddim_steps} DDIM steps",
             "value": n_total * a.steps / elapsed, "unit": "stamps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{1 if a.batch == 1 else 2}]: {a.batch} x {a.res}x{a.res} RGBA stamp(s) per GPU, "
+            "config": {"workload": f"{cfg_name}: {a.batch} x {a.res}x{a.res} RGBA stamp(s) per GPU, "
                                    f"{a.ddim_steps} DDIM steps = {a.ddim_steps - 1} UNet evals (reference quirk), 3 guidance branches, "
                                    "cfg 2.0 / tg 1.0 / tg_steps = steps / context_pad 150, SD-1.5-inpaint UNet + LoRA merged + "
                                    "AutoencoderKL with seeded synthetic weights, conditioning cached",
@@ -171,7 +243,7 @@ def main():
                        "gather": "rccl gather of u8 patches to rank 0" if world > 1 else "none (1 GPU)"},
             "p50_stamp_latency_ms": lat_sorted[len(lat_sorted) // 2], "p95_stamp_latency_ms": lat_sorted[int(len(lat_sorted) * 0.95)],
             "stage_ms": {"pre+vae_encode_x2": stage[0], "denoise_loop": stage[1], "vae_decode+post": stage[2]},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "extra_configs": extras,
         }
         print(json.dumps(line), flush=True)
     D.barrier()

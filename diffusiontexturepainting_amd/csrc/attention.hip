@@ -19,14 +19,22 @@
 // lean: Q is pre-scaled by scale*log2(e) once, exponentials are raw v_exp_f32, the running sum comes
 // out of the PV MFMA for free (a row of ones appended to V^T when the head dim leaves spare rows), and
 // the O^T rescale is skipped while the running maximum is unchanged (wave-uniform test).
+// For d = 40 (UNet level 0, the expensive case: S = 4096) the contraction is padded to 48 anyway, and the first spare column
+// carries the softmax shift: K'[kv][40] = 1 and Q'[q][40] = -m_ref[q], so the MFMA itself delivers s - m_ref and the per-score
+// subtract disappears.  m_ref is an fp16-representable reference near the running row maximum; it is only moved (with the
+// matching O^T rescale) when some row's scores exceed it by more than 2^SHIFT_THR -- fp16 P values hold up to 65504 and
+// keep their 11-bit precision at any magnitude, the fp32 accumulators hold the sums -- so after the first tiles of a head the
+// rescale branch is practically never taken.  P is packed with v_cvt_pkrtz (the row sum comes from the same rounded values
+// through the ones row, so the truncation cancels in the normalisation).
 // Built with -ffast-math: masking uses a finite sentinel, never inf/nan.
 #include "common.h"
 #include <math.h>
 
 namespace {
 
-template <int DP>
+template <int DP, bool SHIFT = false>  // SHIFT: d = 40 in a 48-wide contraction (see the header comment)
 __global__ __launch_bounds__(256, (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1))) void attention_kernel(const AttnParams p) {
+  static_assert(!SHIFT || DP == 48, "the shift column lives in the padding of d = 40");
   constexpr int KS = DP / 16;           // k-steps of the QK^T contraction
   constexpr int DB = (DP + 31) / 32;    // 32-row blocks of O^T
   constexpr int KROW = DP * 2 + 16;     // K tile row stride (bytes): odd multiple of 16 -> conflict free
@@ -34,8 +42,12 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1))) void atte
   constexpr int NCH = DP / 8;
   constexpr int KIT = (64 * NCH + 255) / 256;  // K chunks per thread per tile
   constexpr int VIT = (32 * NCH + 255) / 256;  // V key-pair chunks per thread per tile
-  __shared__ __attribute__((aligned(16))) char Kl[64 * KROW];
-  __shared__ __attribute__((aligned(16))) char Vl[DB * 32 * VROW];
+  // One K / V^T tile buffer, two barriers per 64-key tile.  (Measured: double-buffering the tiles -- one barrier, the next
+  // tile written right after this tile's MFMAs -- was 15 % SLOWER on the level-0 shape: 139 vs 118 us.)
+  constexpr int KBYTES = 64 * KROW, VBYTES = DB * 32 * VROW;
+  constexpr int NBUF = 1;
+  __shared__ __attribute__((aligned(16))) char Kl[NBUF * KBYTES];
+  __shared__ __attribute__((aligned(16))) char Vl[NBUF * VBYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, hf = lane >> 5;
@@ -46,6 +58,9 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1))) void atte
   const f16* Kb = p.K + p.kbs * b + h * D;
   const f16* Vb = p.V + p.vbs * b + h * D;
   const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  // spare contraction column (D % 16 == 8, i.e. d = 40 padded to 48): carries the softmax shift through the QK^T MFMA
+  constexpr int SKS = 2, SHF = 1;           // Q' fragment / half-wave holding column 40 (chunk 2*SKS + SHF = 5)
+  constexpr float SHIFT_THR = 6.0f;         // move the reference when a score exceeds it by more than this (exp2 domain)
 
   constexpr bool ONES = (DP % 32) != 0;  // spare V^T rows exist: row DP holds ones -> O^T row DP = sum_k p
   constexpr int ODB = DP / 32, OREG = ((DP % 32) & 3) + 4 * ((DP % 32) >> 3), OHF = ((DP % 32) >> 2) & 1;
@@ -67,74 +82,124 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1))) void atte
   for (int i = 0; i < DB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-  float m_run = NEG, l_run = 0.f;
+  float m_run = SHIFT ? 0.f : NEG, l_run = 0.f;  // SHIFT: m_run is the fp16-representable reference carried in Q'[40]
 
   // zero the V^T tile once: rows d >= D are never written by the staging loop
-  for (int i = tid; i < DB * 32 * VROW / 16; i += 256) ((f32x4*)Vl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (ONES) {
+  for (int i = tid; i < NBUF * VBYTES / 16; i += 256) ((f32x4*)Vl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < NBUF * KBYTES / 16; i += 256) ((f32x4*)Kl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // padding columns stay zero
+  if (ONES || SHIFT) {
     __syncthreads();
-    if (tid < 64) *(f16*)(Vl + DP * VROW + tid * 2) = (f16)1.0f;
+    for (int b2 = 0; b2 < NBUF; ++b2) {
+      if (ONES && tid < 64) *(f16*)(Vl + b2 * VBYTES + DP * VROW + tid * 2) = (f16)1.0f;
+      if (SHIFT && tid < 64) *(f16*)(Kl + b2 * KBYTES + tid * KROW + D * 2) = (f16)1.0f;  // K'[kv][40] = 1 carries -m_ref into every score
+    }
   }
 
   f16x8 kreg[KIT], vreg[VIT][2];
+  // per-thread staging sources: loop-invariant pointers.  Loads are UNCONDITIONAL (a conditional load costs an exec-mask
+  // branch each and drains vmcnt): threads without a valid chunk read a clamped, valid address and simply do not store;
+  // keys beyond Skv (last tile of a ragged sequence) read the clamped last row -- their scores are masked to NEG below, so
+  // p = 0 multiplies a finite V.  The padding columns of the K tile (D <= c*8 < DP, incl. the SHIFT ones column) are
+  // written once before the loop.
+  // whole waves past the end of the chunk list skip their loads (64 * NCH and 32 * NCH are multiples of 64: wave-uniform)
+  const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+  const f16* ksrc[KIT]; bool kval[KIT]; int kkv[KIT];
+#pragma unroll
+  for (int it = 0; it < KIT; ++it) {
+    const int idx = tid + it * 256;
+    const int kv = idx / NCH, c = idx - kv * NCH;
+    kval[it] = (idx < 64 * NCH) && (c * 8 < D);
+    kkv[it] = min(kv, 63);
+    ksrc[it] = Kb + (kval[it] ? c * 8 : 0);
+  }
+  const f16* vsrc[VIT]; bool vval[VIT]; int vkv[VIT];
+#pragma unroll
+  for (int it = 0; it < VIT; ++it) {
+    const int idx = tid + it * 256;
+    const int c = idx >> 5, pr = idx & 31;
+    vval[it] = (c < NCH) && (c * 8 < D);
+    vkv[it] = 2 * pr;
+    vsrc[it] = Vb + (vval[it] ? c * 8 : 0);
+  }
   auto prefetch = [&](int kv0) {
+    if (kv0 + 64 <= p.Skv) {  // full tile (wave-uniform)
 #pragma unroll
-    for (int it = 0; it < KIT; ++it) {
-      const int idx = tid + it * 256;
-      const int kv = idx / NCH, c = idx - kv * NCH;
-      const bool ok = (idx < 64 * NCH) && (kv0 + kv < p.Skv) && (c * 8 < D);
-      kreg[it] = ok ? *(const f16x8*)(Kb + (size_t)(kv0 + kv) * p.ldk + c * 8) : zero8;
-    }
+      for (int it = 0; it < KIT; ++it)
+        if (wbase + it * 256 < 64 * NCH) kreg[it] = *(const f16x8*)(ksrc[it] + (size_t)(kv0 + kkv[it]) * p.ldk);
 #pragma unroll
-    for (int it = 0; it < VIT; ++it) {
-      const int idx = tid + it * 256;
-      const int c = idx >> 5, pr = idx & 31;
-      const bool okc = (c < NCH) && (c * 8 < D);
-      const int kv = kv0 + 2 * pr;
-      vreg[it][0] = (okc && kv < p.Skv) ? *(const f16x8*)(Vb + (size_t)kv * p.ldv + c * 8) : zero8;
-      vreg[it][1] = (okc && kv + 1 < p.Skv) ? *(const f16x8*)(Vb + (size_t)(kv + 1) * p.ldv + c * 8) : zero8;
+      for (int it = 0; it < VIT; ++it)
+        if (wbase + it * 256 < 32 * NCH) {
+          const f16* v0 = vsrc[it] + (size_t)(kv0 + vkv[it]) * p.ldv;
+          vreg[it][0] = *(const f16x8*)v0;
+          vreg[it][1] = *(const f16x8*)(v0 + p.ldv);
+        }
+    } else {
+      const int last = p.Skv - 1;
+#pragma unroll
+      for (int it = 0; it < KIT; ++it)
+        if (wbase + it * 256 < 64 * NCH) kreg[it] = *(const f16x8*)(ksrc[it] + (size_t)min(kv0 + kkv[it], last) * p.ldk);
+#pragma unroll
+      for (int it = 0; it < VIT; ++it)
+        if (wbase + it * 256 < 32 * NCH) {
+          vreg[it][0] = *(const f16x8*)(vsrc[it] + (size_t)min(kv0 + vkv[it], last) * p.ldv);
+          vreg[it][1] = *(const f16x8*)(vsrc[it] + (size_t)min(kv0 + vkv[it] + 1, last) * p.ldv);
+        }
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int buf) {
+    char* const Kd = Kl + buf * KBYTES;
+    char* const Vd = Vl + buf * VBYTES;
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
       const int idx = tid + it * 256;
       const int kv = idx / NCH, c = idx - kv * NCH;
-      if (idx < 64 * NCH) *(f16x8*)(Kl + kv * KROW + c * 16) = kreg[it];
+      if (kval[it]) *(f16x8*)(Kd + kv * KROW + c * 16) = kreg[it];
     }
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {
       const int idx = tid + it * 256;
       const int c = idx >> 5, pr = idx & 31;
-      if (c < NCH && c * 8 < D) {
+      if (vval[it]) {
         const int o = (2 * pr) & 15;
         const int slot = ((2 * pr) & ~15) | (o & 3) | ((o & 4) << 1) | ((o & 8) >> 1);  // even; key 2pr+1 lands at slot+1
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           f16x2 w = {vreg[it][0][e], vreg[it][1][e]};
-          *(f16x2*)(Vl + (c * 8 + e) * VROW + slot * 2) = w;
+          *(f16x2*)(Vd + (c * 8 + e) * VROW + slot * 2) = w;
         }
       }
     }
   };
 
+  const char* const kfrag0 = Kl + lq * KROW + hf * 16;  // this lane's K / V^T fragment rows (buffer 0)
+  const char* const vfrag0 = Vl + lq * VROW + hf * 16;
   prefetch(0);
-  for (int kv0 = 0; kv0 < p.Skv; kv0 += 64) {
-    __syncthreads();  // previous tile fully consumed (and the initial zero fill is visible)
-    stage();
+  if constexpr (NBUF == 2) {
+    __syncthreads();  // the zero fill / ones columns are visible
+    stage(0);
     __syncthreads();
-    if (kv0 + 64 < p.Skv) prefetch(kv0 + 64);  // in flight while this tile is computed
+  }
+  int buf = 0;
+  for (int kv0 = 0; kv0 < p.Skv; kv0 += 64) {
+    if constexpr (NBUF == 1) {
+      __syncthreads();  // previous tile fully consumed (and the initial zero fill is visible)
+      stage(0);
+      __syncthreads();
+    }
+    const bool more = kv0 + 64 < p.Skv;
+    if (more) prefetch(kv0 + 64);  // in flight while this tile is computed
+    const char* const kfrag = kfrag0 + buf * KBYTES;
+    const char* const vfrag = vfrag0 + buf * VBYTES;
 
     // ---- S^T = K Q^T  (two 32-key blocks)
     f32x16 sacc[2];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-#pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const f16x8 kf = *(const f16x8*)(Kl + (kb * 32 + lq) * KROW + (2 * ks + hf) * 16);
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kb], 0, 0, 0);
+        const f16x8 kf = *(const f16x8*)(kfrag + kb * 32 * KROW + ks * 32);  // immediate offsets off one per-lane base
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : sacc[kb], 0, 0, 0);
       }
     }
     // ---- online softmax over this lane's 32 keys (+ the other half-wave's 32)
@@ -147,43 +212,84 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1))) void atte
           if (kv >= p.Skv) sacc[kb][r] = NEG;
         }
     }
-    float mloc = fmaxf(sacc[0][0], sacc[1][0]);
+    float mloc = fmaxf(fmaxf(sacc[0][0], sacc[1][0]), fmaxf(sacc[0][1], sacc[1][1]));
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(sacc[0][r], sacc[1][r]));
+    for (int r = 2; r < 16; r += 2) mloc = fmaxf(mloc, fmaxf(fmaxf(sacc[0][r], sacc[1][r]), fmaxf(sacc[0][r + 1], sacc[1][r + 1])));
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const float m_new = fmaxf(m_run, mloc);
-    float lsum = 0.f;
     f16x8 pf[2][2];
+    float lsum = 0.f;
+    if constexpr (SHIFT) {
+      // sacc already holds s - m_ref.  First tile: m_ref = 0, take the row maximum as the reference; later: only when it is
+      // exceeded by more than SHIFT_THR.  The new reference is rounded to fp16 so that -m_ref is exact in the Q' fragment.
+      const bool first = (kv0 == 0);
+      if (first || __any(mloc > SHIFT_THR)) {
+        const bool mv = first || (mloc > SHIFT_THR);
+        const float m_new = (float)(f16)fminf(fmaxf(m_run + mloc, -60000.f), 60000.f);
+        const float delta = mv ? (m_new - m_run) : 0.f;
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float pv = __builtin_amdgcn_exp2f(sacc[kb][8 * s + e] - m_new);
-          if (!ONES) lsum += pv;
-          pf[kb][s][e] = (f16)pv;
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[kb][r] -= delta;
+        m_run += delta;
+        if (hf == SHF) qf[SKS][0] = (f16)(-m_run);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 w;
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(sacc[kb][8 * s + e]), p1 = __builtin_amdgcn_exp2f(sacc[kb][8 * s + e + 1]);
+            w[e >> 1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(p0, p1));  // one v_cvt_pkrtz_f16_f32 per pair
+          }
+          pf[kb][s] = __builtin_bit_cast(f16x8, w);
         }
-    // ---- O^T = alpha * O^T + V^T P^T   (rescale only when some row's maximum moved)
-    if (__any(m_new > m_run)) {
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      if (!ONES) l_run *= alpha;
+    } else {
+      const float m_new = fmaxf(m_run, mloc);
 #pragma unroll
-      for (int db = 0; db < DB; ++db)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-      m_run = m_new;
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float pv = __builtin_amdgcn_exp2f(sacc[kb][8 * s + e] - m_new);
+            if (!ONES) lsum += pv;
+            pf[kb][s][e] = (f16)pv;
+          }
+      // ---- O^T = alpha * O^T + V^T P^T   (rescale only when some row's maximum moved)
+      if (__any(m_new > m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        if (!ONES) l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        m_run = m_new;
+      }
+      if (!ONES) l_run += lsum + __shfl_xor(lsum, 32);
     }
-    if (!ONES) l_run += lsum + __shfl_xor(lsum, 32);
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const f16x8 vf = *(const f16x8*)(Vl + (db * 32 + lq) * VROW + (kb * 32 + 16 * s + 8 * hf) * 2);
+          const f16x8 vf = *(const f16x8*)(vfrag + db * 32 * VROW + (kb * 32 + 16 * s) * 2);
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s], oacc[db], 0, 0, 0);
         }
+    }
+    if constexpr (NBUF == 2) {
+      // the other buffer was last read during the previous tile, which every wave left before the previous barrier
+      if (more) stage(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
     }
   }
 
@@ -213,7 +319,8 @@ int dtp_launch_attention(const AttnParams& p, hipStream_t s) {
     return DTP_ERR_ARG;
   }
   dim3 grid((p.Sq + 127) / 128, p.H, p.B), block(256);
-  if (p.D <= 48) hipLaunchKernelGGL((attention_kernel<48>), grid, block, 0, s, p);
+  if (p.D == 40) hipLaunchKernelGGL((attention_kernel<48, true>), grid, block, 0, s, p);
+  else if (p.D <= 48) hipLaunchKernelGGL((attention_kernel<48>), grid, block, 0, s, p);
   else if (p.D <= 64) hipLaunchKernelGGL((attention_kernel<64>), grid, block, 0, s, p);
   else if (p.D <= 80) hipLaunchKernelGGL((attention_kernel<80>), grid, block, 0, s, p);
   else if (p.D <= 160) hipLaunchKernelGGL((attention_kernel<160>), grid, block, 0, s, p);

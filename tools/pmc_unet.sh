@@ -5,5 +5,6 @@ cd /tmp && export TMPDIR=/tmp
 for cnt in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $cnt --output-format csv -d /tmp/pmcu_$cnt -o p -- python /root/repo/tools/pmc_unet.py > /tmp/pmcu_$cnt.log 2>&1
   f=$(find /tmp/pmcu_$cnt -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then python /root/repo/tools/pmc_agg.py $f /root/repo/gpurun_out/r01_pmc_unet_$cnt.csv; else tail -5 /tmp/pmcu_$cnt.log > /root/repo/gpurun_out/r01_pmc_unet_$cnt.err; fi
+  if [ -n "$f" ]; then python /root/repo/tools/pmc_agg.py $f /root/repo/gpurun_out/r02_pmc_unet_$cnt.csv; else tail -5 /tmp/pmcu_$cnt.log > /root/repo/gpurun_out/r02_pmc_unet_$cnt.err; fi
 done
+python tools/pmc_traffic_json.py gpurun_out/r02_pmc_unet_FETCH_SIZE.csv gpurun_out/r02_pmc_unet_WRITE_SIZE.csv gpurun_out/r02_pmc_unet_traffic.json
