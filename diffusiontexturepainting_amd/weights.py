@@ -271,6 +271,132 @@ def load_checkpoint_file(path):
     return {k: v.float() for k, v in sd.items()}
 
 
+def save_checkpoint_file(sd, path):
+    """Inverse of load_checkpoint_file (used by the round-trip tests and by anyone re-packing a checkpoint)."""
+    sd = {k: v.detach().cpu().contiguous() for k, v in sd.items()}
+    if path.endswith(".safetensors"):
+        from safetensors.torch import save_file
+        save_file(sd, path)
+    else:
+        torch.save(sd, path)
+
+
+_OPENAI_LAYER = {"ln_1": "layer_norm1", "ln_2": "layer_norm2", "attn.out_proj": "self_attn.out_proj", "mlp.c_fc": "mlp.fc1",
+                 "mlp.c_proj": "mlp.fc2"}
+
+
+def openai_clip_to_hf(sd, prefix=""):
+    """State dict of OpenAI CLIP ViT-B/32 as `clip.load("ViT-B/32")` names it (trt_inference/image_encoder.py:49; keys
+    `visual.*`, optionally under `prefix`, e.g. "clip." inside image_encoder.pth) -> the HF `CLIPVisionModel` naming this
+    package loads (clip_spec).  The fused nn.MultiheadAttention `in_proj_weight/bias` [3*768, ...] is split q | k | v; the text
+    tower, `logit_scale` and `visual.proj` (set to None by the reference, image_encoder.py:50) are dropped."""
+    v = prefix + "visual."
+    out = {}
+    for k, t in sd.items():
+        if not k.startswith(v):
+            continue
+        k = k[len(v):]
+        if k == "proj":
+            continue
+        if k == "conv1.weight":
+            out["vision_model.embeddings.patch_embedding.weight"] = t
+        elif k == "class_embedding":
+            out["vision_model.embeddings.class_embedding"] = t
+        elif k == "positional_embedding":
+            out["vision_model.embeddings.position_embedding.weight"] = t
+        elif k.startswith("ln_pre."):
+            out["vision_model.pre_layrnorm." + k[7:]] = t  # (sic) the HF attribute name
+        elif k.startswith("ln_post."):
+            out["vision_model.post_layernorm." + k[8:]] = t
+        elif k.startswith("transformer.resblocks."):
+            i, rest = k[len("transformer.resblocks."):].split(".", 1)
+            base = f"vision_model.encoder.layers.{i}."
+            if rest in ("attn.in_proj_weight", "attn.in_proj_bias"):
+                kind = rest.rsplit("_", 1)[1]
+                q, kk, vv = t.chunk(3, dim=0)
+                out[base + "self_attn.q_proj." + kind], out[base + "self_attn.k_proj." + kind], out[base + "self_attn.v_proj." + kind] = q, kk, vv
+            else:
+                mod, kind = rest.rsplit(".", 1)
+                if mod not in _OPENAI_LAYER:
+                    raise KeyError(f"unexpected OpenAI-CLIP key '{prefix}visual.{k}'")
+                out[base + _OPENAI_LAYER[mod] + "." + kind] = t
+        else:
+            raise KeyError(f"unexpected OpenAI-CLIP key '{prefix}visual.{k}'")
+    return {k: t.float() for k, t in out.items()}
+
+
+def hf_clip_to_openai(sd, prefix=""):
+    """Inverse of openai_clip_to_hf (test helper: builds an OpenAI-named dict from the synthetic HF-named tower)."""
+    inv = {v: k for k, v in _OPENAI_LAYER.items()}
+    out = {}
+    p = prefix + "visual."
+    out[p + "conv1.weight"] = sd["vision_model.embeddings.patch_embedding.weight"]
+    out[p + "class_embedding"] = sd["vision_model.embeddings.class_embedding"]
+    out[p + "positional_embedding"] = sd["vision_model.embeddings.position_embedding.weight"]
+    for kind in ("weight", "bias"):
+        out[p + "ln_pre." + kind] = sd["vision_model.pre_layrnorm." + kind]
+        out[p + "ln_post." + kind] = sd["vision_model.post_layernorm." + kind]
+    for i in range(12):
+        b, o = f"vision_model.encoder.layers.{i}.", f"{p}transformer.resblocks.{i}."
+        for kind in ("weight", "bias"):
+            out[o + "attn.in_proj_" + kind] = torch.cat([sd[b + f"self_attn.{n}_proj.{kind}"] for n in "qkv"], dim=0)
+            for hf, oa in inv.items():
+                out[o + oa + "." + kind] = sd[b + hf + "." + kind]
+    return out
+
+
+def split_image_encoder_checkpoint(sd):
+    """`image_encoder.pth` (the ConditionPatchEncoder state dict the reference loads with strict=False, trt_model.py:57-59) ->
+    (clip_sd or None, penc_sd).  The frozen CLIP tower inside it may be stored in OpenAI naming (`clip.visual.*`, what
+    image_encoder.py:49 builds) or in HF naming (`clip.vision_model.*`, the training twin training/image_encoder.py:39) or be
+    absent; the CLIP text tower and anything else the patch encoder does not own is ignored, like strict=False does.  Missing
+    patch-encoder tensors are an error here: there is no pretrained default to fall back on."""
+    spec = patch_encoder_spec()
+    penc = {k: v.float() for k, v in sd.items() if k in spec}
+    check_against_spec(penc, spec, "image_encoder.pth (patch encoder)")
+    clip = None
+    if any(k.startswith("clip.visual.") for k in sd):
+        clip = openai_clip_to_hf(sd, prefix="clip.")
+    elif any(k.startswith("clip.vision_model.") for k in sd):
+        clip = {k[len("clip."):]: v.float() for k, v in sd.items() if k.startswith("clip.vision_model.")}
+    if clip is not None:
+        check_against_spec(clip, clip_spec(), "image_encoder.pth (CLIP tower)")
+        clip = {k: clip[k] for k in clip_spec()}
+    return clip, penc
+
+
+def load_model_files(unet, vae, lora=None, image_encoder=None, clip=None):
+    """Assemble the `weights=` argument of MI355ConditionalInpainter from checkpoint files: `unet` / `vae` =
+    diffusion_pytorch_model.{safetensors,bin} of the runwayml/stable-diffusion-inpainting layout the reference downloads
+    (models.py:1038,1241,1332), `lora` = pytorch_lora_weights.bin (models.py:1042; keys `<module>.processor.<proj>_lora.
+    {down,up}.weight`), `image_encoder` = image_encoder.pth (trt_model.py:57-59), `clip` = an OpenAI- or HF-named ViT-B/32
+    state-dict file when image_encoder.pth does not carry the tower."""
+    nets = dict(unet=load_checkpoint_file(unet), vae=load_checkpoint_file(vae))
+    check_against_spec(nets["unet"], unet_spec(), "unet")
+    check_against_spec(nets["vae"], vae_spec(), "vae")
+    if lora is not None:
+        nets["lora"] = load_checkpoint_file(lora)
+        check_against_spec(nets["lora"], lora_spec(lora_rank_of(nets["lora"])), "lora")
+    if image_encoder is not None:
+        c, nets["penc"] = split_image_encoder_checkpoint(load_checkpoint_file(image_encoder))
+        if clip is not None:
+            raw = load_checkpoint_file(clip)
+            c = openai_clip_to_hf(raw) if any(k.startswith("visual.") for k in raw) else {k: v for k, v in raw.items() if k.startswith("vision_model.")}
+        if c is None:
+            raise ValueError("image_encoder.pth carries no CLIP tower: pass clip=<ViT-B/32 state-dict file>")
+        check_against_spec(c, clip_spec(), "clip")
+        nets["clip"] = c
+    return nets
+
+
+def lora_rank_of(lora_sd):
+    """LoRA rank of a pytorch_lora_weights.bin state dict (rows of any `...down.weight`)."""
+    for k, v in lora_sd.items():
+        if k.endswith("_lora.down.weight"):
+            return int(v.shape[0])
+    raise ValueError("no '*_lora.down.weight' tensor in the LoRA file")
+
+
 def check_against_spec(sd, spec, what):
     missing = [k for k in spec if k not in sd]
     bad = [k for k in spec if k in sd and tuple(sd[k].shape) != tuple(spec[k])]

@@ -266,3 +266,30 @@ def test_stamp_enqueue_does_not_block_the_host():
     c2 = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
     torch.cuda.synchronize()
     assert torch.equal(c2, a) and not torch.equal(c1, a)
+
+
+def test_weights_from_checkpoint_files_give_identical_stamps(tmp_path, sd):
+    """f3: diffusers-layout files (fp16 .safetensors UNet / VAE, pytorch_lora_weights.bin, image_encoder.pth with the OpenAI-named
+    CLIP tower inside) -> weights.load_model_files -> the operator; bit-identical to the same tensors handed over in memory."""
+    from diffusiontexturepainting_amd import weights as W
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    half = {n: {k: v.half().float() for k, v in sd[n].items()} for n in ("unet", "vae")}
+    W.save_checkpoint_file({k: v.half() for k, v in sd["unet"].items()}, str(tmp_path / "unet.safetensors"))
+    W.save_checkpoint_file({k: v.half() for k, v in sd["vae"].items()}, str(tmp_path / "vae.safetensors"))
+    W.save_checkpoint_file(sd["lora"], str(tmp_path / "pytorch_lora_weights.bin"))
+    ienc = dict(sd["penc"])
+    ienc.update(W.hf_clip_to_openai(sd["clip"], prefix="clip."))
+    ienc["clip.logit_scale"] = torch.tensor(4.6)
+    W.save_checkpoint_file(ienc, str(tmp_path / "image_encoder.pth"))
+    nets = W.load_model_files(str(tmp_path / "unet.safetensors"), str(tmp_path / "vae.safetensors"),
+                              lora=str(tmp_path / "pytorch_lora_weights.bin"), image_encoder=str(tmp_path / "image_encoder.pth"))
+    assert set(nets) == {"unet", "vae", "lora", "clip", "penc"}
+    outs = []
+    for w in (nets, dict(unet=half["unet"], vae=half["vae"], lora=sd["lora"], clip=sd["clip"], penc=sd["penc"])):
+        m = MI355ConditionalInpainter(R, device=0, weights=w, max_batch=1)
+        m.set_brush(torch.rand(3, 80, 64, generator=torch.Generator().manual_seed(1)))
+        canvas, _, _, _, lat, eps = _inputs(1, R, 950)
+        outs.append((m.generate_raw(canvas, latents=lat, vae_eps=eps, steps=3, context_pad=5, tg_steps=3).cpu(), m.conditioning[0].cpu()))
+        m._lib.dtp_destroy(m._h)
+        m._h = None
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
