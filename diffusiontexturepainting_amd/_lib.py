@@ -8,6 +8,7 @@ import torch  # noqa: F401  -- must come first: libdtp.so has to bind to the HIP
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DTP_LIB") or os.path.join(_HERE, "libdtp.so")  # DTP_LIB: A/B another build of the same ABI
 _lib = None
+MAX_SLOTS = 16  # DTP_MAX_SLOTS
 
 
 class DtpError(RuntimeError):
@@ -64,6 +65,10 @@ SYMBOLS = {
     "dtp_set_conditioning": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "dtp_get_conditioning": (_i, [_vp, _vp, _vp, _vp]),
     "dtp_stamp": (_i, [_vp, _vp, C.POINTER(Settings), _vp, _vp, _vp, _i, _vp]),
+    "dtp_stamp_slots": (_i, [_vp, _vp, C.POINTER(Settings), _vp, _vp, _vp, _i, C.POINTER(_i), _vp]),
+    "dtp_set_brush_slot": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
+    "dtp_set_conditioning_slot": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "dtp_get_conditioning_slot": (_i, [_vp, _i, _vp, _vp, _vp]),
     "dtp_ddim_tables": (_i, [_i, C.POINTER(_i64), C.POINTER(_f), C.POINTER(_f)]),
     "dtp_last_stamp_times": (_i, [_vp, C.POINTER(_f * 3)]),
     "dtp_last_stamp_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),

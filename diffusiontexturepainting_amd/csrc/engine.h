@@ -143,6 +143,8 @@ struct UNetProg {
   // (B, NB) split, not only on N = NB*B (B=2,NB=3 and B=3,NB=2 share a program)
   unsigned long long kv_ver = 0;
   int kv_B = 0, kv_NB = 0;
+  std::vector<int> kv_slots;                       // conditioning slot of every stamp the K/V were built for
+  std::vector<unsigned long long> kv_slot_ver;     // ... and the version of that slot at the time
 };
 struct VaeEncProg {
   int B = 0;
@@ -206,10 +208,14 @@ struct Ctx {
   int sched_steps = -1;      // step count the table/coefficients were built for
 
   // conditioning
-  float* cond32 = nullptr;   // [2][14][768] : cond, uncond
-  float* brush32 = nullptr;  // [3][R][R]
-  bool have_cond = false;
-  unsigned long long cond_version = 0;
+  // conditioning SLOTS: one brush per slot (a client of the multi-client server); slot 0 is what the single-brush entry
+  // points use.  cond32 [DTP_MAX_SLOTS][2][14][768] (cond, uncond), brush32 [DTP_MAX_SLOTS][3][R][R]
+  float* cond32 = nullptr;
+  float* brush32 = nullptr;
+  bool slot_set[DTP_MAX_SLOTS] = {};
+  unsigned long long slot_version[DTP_MAX_SLOTS] = {};  // bumped by every (re)definition of the slot
+  unsigned long long cond_version = 0;                  // bumped by every change of any slot
+  int* slot_map = nullptr;   // device int[maxB]: conditioning slot of stamp b of the stamp batch being processed
 
   // stamp state
   float* x32 = nullptr;       // [maxB][h][w][4] current latent (fp32, NHWC)

@@ -310,9 +310,14 @@ static int build_ienc(Ctx* c, IencBufs& ib) {
   return DTP_OK;
 }
 
-extern "C" int dtp_set_brush(dtp_ctx* ctx, const float* image, int H, int W, float* image_out, dtp_stream s_) {
+extern "C" int dtp_set_brush(dtp_ctx* ctx, const float* image, int H, int W, float* image_out, dtp_stream s) {
+  return dtp_set_brush_slot(ctx, 0, image, H, W, image_out, s);
+}
+
+extern "C" int dtp_set_brush_slot(dtp_ctx* ctx, int slot, const float* image, int H, int W, float* image_out, dtp_stream s_) {
   Ctx* c = (Ctx*)ctx;
   hipStream_t s = (hipStream_t)s_;
+  if (slot < 0 || slot >= DTP_MAX_SLOTS) { dtp_set_error("dtp_set_brush: slot %d outside 0..%d", slot, DTP_MAX_SLOTS - 1); return DTP_ERR_ARG; }
   if (!c || !c->finalized) { dtp_set_error("dtp_set_brush: weights not finalized"); return DTP_ERR_STATE; }
   if (!c->ienc.present) { dtp_set_error("dtp_set_brush: image-encoder weights (clip.*, penc.*) were not loaded"); return DTP_ERR_STATE; }
   if (!image || H < 1 || W < 1) { dtp_set_error("dtp_set_brush: bad image"); return DTP_ERR_ARG; }
@@ -320,14 +325,16 @@ extern "C" int dtp_set_brush(dtp_ctx* ctx, const float* image, int H, int W, flo
   IencBufs& ib = c->ienc_bufs;
   if (!ib.built) RC(build_ienc(c, ib));
   const int R = c->R;
-  hipLaunchKernelGGL(crop_resize_kernel, dim3(1024), dim3(256), 0, s, image, H, W, c->brush32, R);
-  if (image_out) HIP_CHECK(hipMemcpyAsync(image_out, c->brush32, (size_t)3 * R * R * 4, hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(bicubic224_norm_kernel, dim3(588), dim3(256), 0, s, c->brush32, R, ib.img224);
+  float* const brush = c->brush32 + (size_t)slot * 3 * R * R;
+  float* const cond = c->cond32 + (size_t)slot * 2 * 14 * 768;
+  hipLaunchKernelGGL(crop_resize_kernel, dim3(1024), dim3(256), 0, s, image, H, W, brush, R);
+  if (image_out) HIP_CHECK(hipMemcpyAsync(image_out, brush, (size_t)3 * R * R * 4, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(bicubic224_norm_kernel, dim3(588), dim3(256), 0, s, brush, R, ib.img224);
   hipLaunchKernelGGL(patchify_kernel, dim3(2048), dim3(256), 0, s, ib.img224, ib.patchA);
   RC(ib.prog.run(s, 0));
-  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(42), dim3(256), 0, s, ib.out16, c->cond32, 14 * 768);
-  HIP_CHECK(hipMemcpyAsync(c->cond32 + 14 * 768, c->ienc.uncond, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
-  c->have_cond = true;
-  ++c->cond_version;
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(42), dim3(256), 0, s, ib.out16, cond, 14 * 768);
+  HIP_CHECK(hipMemcpyAsync(cond + 14 * 768, c->ienc.uncond, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
+  c->slot_set[slot] = true;
+  c->slot_version[slot] = ++c->cond_version;
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }

@@ -83,13 +83,14 @@ __global__ void dilate_col_kernel(const float* __restrict__ tmp, float* __restri
 
 // trt_model.py:103-109 + handler.py:25-33: canvas -> VAE-encoder inputs (NHWC f16, 8 channels,
 // batch [masked x B | context x B]) and the two latent-resolution masks (nearest, 1 = paint).
-__global__ void prep_kernel(const float* __restrict__ canvas, const float* __restrict__ brush, const float* __restrict__ dil,
-                            f16* __restrict__ enc_in, float* __restrict__ masks, int B, int R) {
+__global__ void prep_kernel(const float* __restrict__ canvas, const float* __restrict__ brush_slots, const int* __restrict__ slot_map,
+                            const float* __restrict__ dil, f16* __restrict__ enc_in, float* __restrict__ masks, int B, int R) {
   const int HW = R * R, h = R / 8;
   const long long total = (long long)B * HW;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int b = (int)(i / HW), pix = (int)(i - (long long)b * HW);
     const float* cb = canvas + (size_t)b * 4 * HW;
+    const float* brush = brush_slots + (size_t)slot_map[b] * 3 * HW;  // this stamp's brush (hint image source)
     const float a = cb[3 * HW + pix];
     const float hint = 1.0f - dil[i];
     f16x8 m8, c8;
@@ -192,15 +193,22 @@ __global__ void finish_kernel(const float* __restrict__ dec, const float* __rest
   }
 }
 
-// ctx16[n][14][768]: branch 0 <- uncond, branches 1.. <- cond  (inpaint_pipeline.py:140)
-__global__ void build_ctx_kernel(const float* __restrict__ cond2, f16* __restrict__ ctx16, int B, int NB) {
+// ctx16[n][14][768]: branch 0 <- uncond, branches 1.. <- cond  (inpaint_pipeline.py:140), each from the stamp's own slot
+__global__ void build_ctx_kernel(const float* __restrict__ cond_slots, const int* __restrict__ slot_map, f16* __restrict__ ctx16, int B,
+                                 int NB) {
   const int per = 14 * 768;
   const long long total = (long long)NB * B * per;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int n = (int)(i / per), j = (int)(i - (long long)n * per);
-    const int br = n / B;
-    ctx16[i] = (f16)cond2[(br == 0 ? per : 0) + j];
+    const int br = n / B, b = n - br * B;
+    ctx16[i] = (f16)cond_slots[(size_t)slot_map[b] * 2 * per + (br == 0 ? per : 0) + j];
   }
+}
+
+struct SlotArgs { int s[64]; };
+// the per-stamp slot ids travel as a kernel argument (no host staging buffer to keep alive, no sync)
+__global__ void set_slots_kernel(int* __restrict__ dst, SlotArgs a, int B) {
+  if ((int)threadIdx.x < B) dst[threadIdx.x] = a.s[threadIdx.x];
 }
 
 // cfg / tg / tg_steps travel as kernel ARGUMENTS into the device parameter block the captured step kernels read: no host
@@ -234,8 +242,9 @@ int stamp_init(Ctx* c) {
   RC(ctx_persistent(c, c->maxB * 4 * RR * 4, &p, true)); c->canvas32 = (float*)p;
   RC(ctx_persistent(c, 2 * c->maxB * RR * 4, &p, true)); c->alpha_tmp = (float*)p;
   RC(ctx_persistent(c, (4 + 4 * 1000) * 4, &p, true)); c->stamp_params = (float*)p;
-  RC(ctx_persistent(c, 2 * 14 * 768 * 4, &p, true)); c->cond32 = (float*)p;
-  RC(ctx_persistent(c, 3 * RR * 4, &p, true)); c->brush32 = (float*)p;
+  RC(ctx_persistent(c, (size_t)DTP_MAX_SLOTS * 2 * 14 * 768 * 4, &p, true)); c->cond32 = (float*)p;
+  RC(ctx_persistent(c, (size_t)DTP_MAX_SLOTS * 3 * RR * 4, &p, true)); c->brush32 = (float*)p;
+  RC(ctx_persistent(c, 64 * sizeof(int), &p, true)); c->slot_map = (int*)p;
   RC(ctx_persistent(c, 256, &p, true)); c->finite_flag = (int*)p;
   return DTP_OK;
 }
@@ -313,35 +322,55 @@ int dtp_finalize_weights(dtp_ctx* ctx) {
   return DTP_OK;
 }
 
-int dtp_set_conditioning(dtp_ctx* ctx, const float* cond, const float* uncond, const float* brush, dtp_stream s_) {
+int dtp_set_conditioning_slot(dtp_ctx* ctx, int slot, const float* cond, const float* uncond, const float* brush, dtp_stream s_) {
   Ctx* c = (Ctx*)ctx;
   hipStream_t s = (hipStream_t)s_;
   if (!c || !c->finalized || !cond || !uncond || !brush) { dtp_set_error("dtp_set_conditioning: bad state/argument"); return DTP_ERR_STATE; }
+  if (slot < 0 || slot >= DTP_MAX_SLOTS) { dtp_set_error("dtp_set_conditioning: slot %d outside 0..%d", slot, DTP_MAX_SLOTS - 1); return DTP_ERR_ARG; }
   HIP_CHECK(hipSetDevice(c->device));
-  HIP_CHECK(hipMemcpyAsync(c->cond32, cond, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
-  HIP_CHECK(hipMemcpyAsync(c->cond32 + 14 * 768, uncond, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
-  HIP_CHECK(hipMemcpyAsync(c->brush32, brush, (size_t)3 * c->R * c->R * 4, hipMemcpyDeviceToDevice, s));
-  c->have_cond = true;
-  ++c->cond_version;
+  float* dst = c->cond32 + (size_t)slot * 2 * 14 * 768;
+  HIP_CHECK(hipMemcpyAsync(dst, cond, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(dst + 14 * 768, uncond, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(c->brush32 + (size_t)slot * 3 * c->R * c->R, brush, (size_t)3 * c->R * c->R * 4, hipMemcpyDeviceToDevice, s));
+  c->slot_set[slot] = true;
+  c->slot_version[slot] = ++c->cond_version;
   return DTP_OK;
 }
 
-int dtp_get_conditioning(dtp_ctx* ctx, float* cond, float* uncond, dtp_stream s_) {
+int dtp_set_conditioning(dtp_ctx* ctx, const float* cond, const float* uncond, const float* brush, dtp_stream s) {
+  return dtp_set_conditioning_slot(ctx, 0, cond, uncond, brush, s);
+}
+
+int dtp_get_conditioning_slot(dtp_ctx* ctx, int slot, float* cond, float* uncond, dtp_stream s_) {
   Ctx* c = (Ctx*)ctx;
   hipStream_t s = (hipStream_t)s_;
-  if (!c || !c->have_cond) { dtp_set_error("dtp_get_conditioning: no brush set"); return DTP_ERR_STATE; }
-  HIP_CHECK(hipMemcpyAsync(cond, c->cond32, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
-  HIP_CHECK(hipMemcpyAsync(uncond, c->cond32 + 14 * 768, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
+  if (!c || slot < 0 || slot >= DTP_MAX_SLOTS || !c->slot_set[slot]) { dtp_set_error("dtp_get_conditioning: no brush set in slot %d", slot); return DTP_ERR_STATE; }
+  const float* src = c->cond32 + (size_t)slot * 2 * 14 * 768;
+  HIP_CHECK(hipMemcpyAsync(cond, src, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(uncond, src + 14 * 768, 14 * 768 * 4, hipMemcpyDeviceToDevice, s));
   return DTP_OK;
 }
 
+int dtp_get_conditioning(dtp_ctx* ctx, float* cond, float* uncond, dtp_stream s) { return dtp_get_conditioning_slot(ctx, 0, cond, uncond, s); }
+
 int dtp_stamp(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const float* latents, const float* vae_eps,
-              void* out, int B, dtp_stream s_) {
+              void* out, int B, dtp_stream s) {
+  return dtp_stamp_slots(ctx, canvas, st, latents, vae_eps, out, B, nullptr, s);
+}
+
+int dtp_stamp_slots(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const float* latents, const float* vae_eps,
+                    void* out, int B, const int* slots, dtp_stream s_) {
   Ctx* c = (Ctx*)ctx;
   hipStream_t s = (hipStream_t)s_;
   if (!c || !c->finalized) { dtp_set_error("dtp_stamp: weights not finalized"); return DTP_ERR_STATE; }
-  if (!c->have_cond) { dtp_set_error("dtp_stamp: no brush set (call dtp_set_brush / dtp_set_conditioning)"); return DTP_ERR_STATE; }
   if (!canvas || !st || !latents || !out || B < 1 || B > c->maxB) { dtp_set_error("dtp_stamp: bad argument (B=%d, max %d)", B, c->maxB); return DTP_ERR_ARG; }
+  SlotArgs sa = {};
+  for (int b = 0; b < B; ++b) {
+    const int sl = slots ? slots[b] : 0;
+    if (sl < 0 || sl >= DTP_MAX_SLOTS) { dtp_set_error("dtp_stamp: slot %d of stamp %d outside 0..%d", sl, b, DTP_MAX_SLOTS - 1); return DTP_ERR_ARG; }
+    if (!c->slot_set[sl]) { dtp_set_error("dtp_stamp: no brush set in slot %d (call dtp_set_brush / dtp_set_conditioning)", sl); return DTP_ERR_STATE; }
+    sa.s[b] = sl;
+  }
   if (st->steps < 2 || st->steps > 999) { dtp_set_error("dtp_stamp: steps=%d outside 2..999", st->steps); return DTP_ERR_ARG; }
   if (st->context_pad < 1) { dtp_set_error("dtp_stamp: context_pad must be >= 1"); return DTP_ERR_ARG; }
   HIP_CHECK(hipSetDevice(c->device));
@@ -383,15 +412,22 @@ int dtp_stamp(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const f
     c->sched_steps = steps;
   }
   hipLaunchKernelGGL(set_header_kernel, dim3(1), dim3(64), 0, s, c->stamp_params, st->cfg_weight, st->tg_weight, (float)st->tg_steps);
+  hipLaunchKernelGGL(set_slots_kernel, dim3(1), dim3(64), 0, s, c->slot_map, sa, B);
 
   // ---- cross-attention K/V for the current brush
   for (UNetProg* up : {u3, u2}) {
     if (!up) continue;
     const int NB = up->N / B;
-    if (up->kv_ver != c->cond_version || up->kv_B != B || up->kv_NB != NB) {
-      hipLaunchKernelGGL(build_ctx_kernel, dim3(nblk((long long)up->N * 14 * 768)), dim3(256), 0, s, c->cond32, up->ctx16, B, NB);
+    // the cached per-stamp matrices are valid for exactly this (B, NB) split, these slots and these slot versions
+    bool valid = up->kv_ver != 0 && up->kv_B == B && up->kv_NB == NB && (int)up->kv_slots.size() == B;
+    for (int b = 0; valid && b < B; ++b) valid = up->kv_slots[b] == sa.s[b] && up->kv_slot_ver[b] == c->slot_version[sa.s[b]];
+    if (!valid) {
+      hipLaunchKernelGGL(build_ctx_kernel, dim3(nblk((long long)up->N * 14 * 768)), dim3(256), 0, s, c->cond32, c->slot_map, up->ctx16, B, NB);
       RC(up->kv.run(s, 0));
       up->kv_ver = c->cond_version; up->kv_B = B; up->kv_NB = NB;
+      up->kv_slots.assign(sa.s, sa.s + B);
+      up->kv_slot_ver.resize(B);
+      for (int b = 0; b < B; ++b) up->kv_slot_ver[b] = c->slot_version[sa.s[b]];
     }
   }
 
@@ -409,7 +445,7 @@ int dtp_stamp(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const f
   const int first_nb = tg_evals > 0 ? 3 : 2;
   UNetProg* first = tg_evals > 0 ? u3 : u2;
   RC(run_stage(c, ((long long)B << 32) | (vae_eps ? 2 : 0) | (first_nb == 3 ? 1 : 0) | (1LL << 60), s, [&](hipStream_t q) -> int {
-    hipLaunchKernelGGL(prep_kernel, dim3(nblk((long long)B * HW)), dim3(256), 0, q, c->canvas32, c->brush32,
+    hipLaunchKernelGGL(prep_kernel, dim3(nblk((long long)B * HW)), dim3(256), 0, q, c->canvas32, c->brush32, c->slot_map,
                        c->alpha_tmp + (size_t)c->maxB * HW, enc->in8, sb->masks, B, R);
     RC(enc->main.run(q, 0));
     RC(launch_vae_sample(c, enc->moments, vae_eps ? sb->eps : nullptr, sb->ml, 2 * B, VAE_SCALE, q));

@@ -427,6 +427,7 @@ extern "C" int dtp_unet(dtp_ctx* ctx, const float* sample, float timestep, const
   RC(dtp_launch_nchw_f32_to_nhwc_f16(sample, up->in16, N, 9, hw, 16, s));
   HIP_CHECK(hipMemcpyAsync(up->ctx16, ctx_f16, (size_t)N * 14 * 768 * 2, hipMemcpyDeviceToDevice, s));
   up->kv_ver = 0;  // K/V now belong to the caller's conditioning
+  up->kv_slots.clear();
   RC(up->kv.run(s, 0));
   RC(up->main.run(s, 0));
   return launch_nhwc_f32_to_nchw(up->out32, out, N, 4, hw, 4, s);

@@ -56,6 +56,7 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
         self.stream = torch.cuda.Stream(device=self._device)
         self.conditioning = None
         self.image = None
+        self._slots = {}  # conditioning slot -> (image [1,3,R,R], (cond, uncond))
         self.last_times_ms = None
         self._check_finite = False
 
@@ -93,34 +94,44 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
     def _s(self):
         return C.c_void_p(self.stream.cuda_stream)
 
-    def set_brush(self, image):
-        """image: 3 x H x W float32 0..1 (trt_model.py:79-88).  Sets `.image` [1,3,R,R] on the device."""
+    def set_brush(self, image, slot=0):
+        """image: 3 x H x W float32 0..1 (trt_model.py:79-88).  Sets `.image` [1,3,R,R] on the device.
+        `slot` (0..15) selects a conditioning slot: the multi-client server keeps one brush per client and batches their stamps
+        (`generate(..., slots=[...])`); slot 0 is the reference's single brush."""
         img = image.detach().to(self._device, torch.float32).contiguous()
         if img.dim() != 3 or img.shape[0] != 3:
             raise ValueError(f"set_brush expects a 3 x H x W image, got {tuple(img.shape)}")
         out = torch.empty(1, 3, self._resolution, self._resolution, dtype=torch.float32, device=self._device)
         self.stream.wait_stream(torch.cuda.current_stream(self._device))
         with torch.cuda.stream(self.stream):
-            check(self._lib.dtp_set_brush(self._h, ptr(img), img.shape[1], img.shape[2], ptr(out), self._s()), "dtp_set_brush")
+            check(self._lib.dtp_set_brush_slot(self._h, int(slot), ptr(img), img.shape[1], img.shape[2], ptr(out), self._s()), "dtp_set_brush")
             cond = torch.empty(2, 1, 14, 768, dtype=torch.float32, device=self._device)
-            check(self._lib.dtp_get_conditioning(self._h, ptr(cond[0]), ptr(cond[1]), self._s()), "dtp_get_conditioning")
+            check(self._lib.dtp_get_conditioning_slot(self._h, int(slot), ptr(cond[0]), ptr(cond[1]), self._s()), "dtp_get_conditioning")
         self.stream.synchronize()
-        self.image = out
-        self.conditioning = (cond[0], cond[1])
+        self._slots[int(slot)] = (out, (cond[0], cond[1]))
+        if slot == 0:
+            self.image = out
+            self.conditioning = (cond[0], cond[1])
 
-    def set_conditioning(self, image_embeds, negative_embeds, image):
+    def slot_image(self, slot):
+        """The resized brush image [1,3,R,R] of a conditioning slot (what `.image` is for slot 0)."""
+        return self._slots[int(slot)][0]
+
+    def set_conditioning(self, image_embeds, negative_embeds, image, slot=0):
         """Install precomputed conditioning ([1,14,768] each) and the R x R brush image [1,3,R,R]."""
         ce = image_embeds.detach().to(self._device, torch.float32).reshape(14, 768).contiguous()
         ue = negative_embeds.detach().to(self._device, torch.float32).reshape(14, 768).contiguous()
         img = image.detach().to(self._device, torch.float32).reshape(3, self._resolution, self._resolution).contiguous()
         torch.cuda.current_stream(self._device).synchronize()
-        check(self._lib.dtp_set_conditioning(self._h, ptr(ce), ptr(ue), ptr(img), self._s()), "dtp_set_conditioning")
+        check(self._lib.dtp_set_conditioning_slot(self._h, int(slot), ptr(ce), ptr(ue), ptr(img), self._s()), "dtp_set_conditioning")
         self.stream.synchronize()
-        self.image = img.unsqueeze(0)
-        self.conditioning = (ce.unsqueeze(0), ue.unsqueeze(0))
+        self._slots[int(slot)] = (img.unsqueeze(0), (ce.unsqueeze(0), ue.unsqueeze(0)))
+        if slot == 0:
+            self.image = img.unsqueeze(0)
+            self.conditioning = (ce.unsqueeze(0), ue.unsqueeze(0))
 
-    def _stamp(self, canvas, settings, composite, latents=None, vae_eps=None, output_u8=False):
-        if self.conditioning is None:
+    def _stamp(self, canvas, settings, composite, latents=None, vae_eps=None, output_u8=False, slots=None):
+        if not self._slots:
             raise _lib.DtpError("no brush set: call set_brush() first")
         R, h = self._resolution, self._resolution // 8
         canvas = canvas.detach().to(self._device, torch.float32).contiguous()
@@ -139,8 +150,14 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
         out = (torch.empty(B, R, R, 3, dtype=torch.uint8, device=self._device) if output_u8
                else torch.empty(B, 3, R, R, dtype=torch.float32, device=self._device))
         self.stream.wait_stream(torch.cuda.current_stream(self._device))
-        check(self._lib.dtp_stamp(self._h, ptr(canvas), C.byref(st), ptr(latents), ptr(vae_eps), ptr(out), B, self._s()),
-              "dtp_stamp")
+        if slots is None:
+            check(self._lib.dtp_stamp(self._h, ptr(canvas), C.byref(st), ptr(latents), ptr(vae_eps), ptr(out), B, self._s()), "dtp_stamp")
+        else:
+            if len(slots) != B:
+                raise ValueError(f"{len(slots)} slots for {B} stamps")
+            arr = (C.c_int * B)(*[int(v) for v in slots])
+            check(self._lib.dtp_stamp_slots(self._h, ptr(canvas), C.byref(st), ptr(latents), ptr(vae_eps), ptr(out), B, arr, self._s()),
+                  "dtp_stamp_slots")
         torch.cuda.current_stream(self._device).wait_stream(self.stream)
         # keep the inputs alive until the stream has consumed them
         for t in (canvas, latents, vae_eps, out):
@@ -150,19 +167,20 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
             raise _lib.DtpError("stamp produced NaN/inf (check_finite): latents or decoded image are not finite")
         return out
 
-    def generate_raw(self, canvas, latents=None, vae_eps=None, **settings):
+    def generate_raw(self, canvas, latents=None, vae_eps=None, slots=None, **settings):
         """canvas B x 4 x R x R 0..1 -> B x 3 x R x R 0..1 (trt_model.py:90-121).  `latents`
         ([B,4,h,w]) / `vae_eps` ([2,B,4,h,w]; False = use the latent mean) override the internal
         generator -- the parity tests feed CPU-generated noise through them."""
-        return self._stamp(canvas, settings, composite=False, latents=latents, vae_eps=vae_eps)
+        return self._stamp(canvas, settings, composite=False, latents=latents, vae_eps=vae_eps, slots=slots)
 
-    def generate(self, canvas, latents=None, vae_eps=None, **settings):
-        """generate_raw + alpha composite (model_base.py:51-58), fused into the final kernel."""
-        return self._stamp(canvas, settings, composite=True, latents=latents, vae_eps=vae_eps)
+    def generate(self, canvas, latents=None, vae_eps=None, slots=None, **settings):
+        """generate_raw + alpha composite (model_base.py:51-58), fused into the final kernel.  `slots`: one conditioning slot per
+        stamp of the batch (stamps of different clients / brushes in one call); None = slot 0 for all."""
+        return self._stamp(canvas, settings, composite=True, latents=latents, vae_eps=vae_eps, slots=slots)
 
-    def generate_u8(self, canvas, composite=True, **settings):
+    def generate_u8(self, canvas, composite=True, slots=None, **settings):
         """Same as generate() but returns the handler's wire image: uint8 HWC, truncated (handler.py:55-56)."""
-        return self._stamp(canvas, settings, composite=composite, output_u8=True)
+        return self._stamp(canvas, settings, composite=composite, output_u8=True, slots=slots)
 
     def stage_times_ms(self):
         """[vae_encoder x2 + pre, denoise loop, vae + post] GPU ms of the last stamp (print_summary, sdp:486-503)."""

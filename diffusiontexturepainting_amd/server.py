@@ -1,0 +1,253 @@
+"""Serving core of the texture-painter backend: what trt_inference/run.py + handler.py do around the operator, plus the
+things a multi-client deployment needs:
+
+  * `StampHandler` -- the body of InpaintWebSocketHandler (handler.py:78-123) without the web framework: bytes in (the wire
+    format of server_io), bytes out through a `write_message(bytes)` callback.  A tornado handler is three lines on top of it
+    (`handler.on_message = lambda self, m: core.on_message(self.client_id, m, self.write_message)`).
+  * `StampQueue` -- one per GPU replica.  Stamps of one stroke are serially dependent (the next canvas is rendered from the
+    previous result, kit_app .../ui/brush.py:185-194), so ONE client never has two stamps in flight; DIFFERENT clients are
+    independent.  The queue collects the stamps that are pending at the same time, groups those with equal inference
+    settings and runs each group as one batched call (the B <= max_batch launch programs), every stamp conditioned on its
+    own client's brush through a conditioning slot.
+  * `StampServer` -- routes every new client to the least-loaded replica (one model / process-local GPU each) and keeps it
+    there (its brush lives in that replica's slot table).
+  * error replies -- the reference logs an exception and sends nothing (handler.py:83-89), which leaves the Kit client waiting
+    forever.  With `error_replies=True` a failed request is answered with a RETURN_ERROR frame
+    ([type u8 = 5][len u32 LE][utf-8 message]); off by default because the unchanged client does not know the type.
+
+Nothing here touches the GPU directly: the model only has to provide resolution() / device() / set_brush(img, slot) /
+slot_image(slot) / generate(canvas, slots=[...], **settings) -- MI355ConditionalInpainter does, and so do the CPU fakes of the
+tests.
+"""
+import logging
+import queue
+import struct
+import threading
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import server_io as sio
+
+logger = logging.getLogger(__name__)
+
+RETURN_ERROR = 5  # extension of server_io.RequestType (opt-in, see module docstring)
+
+
+def encode_error_response(message):
+    raw = message.encode("utf-8", "replace")[:4096]
+    return bytes([RETURN_ERROR]) + struct.pack("<I", len(raw)) + raw
+
+
+def decode_error_response(frame):
+    (n,) = struct.unpack_from("<I", frame, 1)
+    return frame[5:5 + n].decode("utf-8", "replace")
+
+
+def preview_mask(res):
+    """handler.py:48-52: the top-left quadrant is 'already painted'."""
+    m = torch.zeros(1, 1, res, res)
+    m[..., : res // 2, : res // 2] = 1
+    return m
+
+
+def np_to_torch(img):
+    """handler.py:59-60."""
+    return torch.from_numpy(np.array(img)).to(torch.float32).permute(2, 0, 1) / 255  # np.array: a writable copy of the read-only wire buffer
+
+
+def torch_to_np(img):
+    """handler.py:55-56 (truncating)."""
+    return (img.detach() * 255).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+
+
+@dataclass
+class _Job:
+    kind: str                      # "brush" | "stamp"
+    slot: int
+    settings: dict
+    payload: object                # brush image [3,H,W] f32 / canvas [4,R,R] f32
+    reply: callable                # reply(bytes)
+    done: threading.Event = field(default_factory=threading.Event)
+    error: str = None
+
+
+def _settings_key(s):
+    return tuple((k, float(s[k])) for k in ("steps", "context_pad", "tg_steps", "cfg_weight", "tg_weight") if k in s)
+
+
+class StampQueue:
+    """Work queue of ONE replica (one model on one GPU).  A worker thread drains it: brush changes run alone (they re-encode
+    a slot), stamps pending at the same time are grouped by settings and batched."""
+
+    def __init__(self, model, max_batch=8, error_replies=False, gather_window_s=0.002, n_slots=16):
+        self.model, self.max_batch, self.error_replies, self.window = model, int(max_batch), error_replies, gather_window_s
+        self.q = queue.Queue()
+        self.free_slots = list(range(n_slots))
+        self.clients = {}              # client id -> slot
+        self.batch_sizes = []          # size of every batched stamp call (observability / tests)
+        self.lock = threading.Lock()
+        self.worker = threading.Thread(target=self._run, daemon=True)
+        self.stopping = False
+        self.worker.start()
+
+    # ---- client bookkeeping
+    def attach(self, client_id):
+        with self.lock:
+            if client_id in self.clients:
+                return self.clients[client_id]
+            if not self.free_slots:
+                raise RuntimeError("no free conditioning slot on this replica")
+            self.clients[client_id] = self.free_slots.pop(0)
+            return self.clients[client_id]
+
+    def detach(self, client_id):
+        with self.lock:
+            slot = self.clients.pop(client_id, None)
+            if slot is not None:
+                self.free_slots.append(slot)
+
+    def load(self):
+        with self.lock:
+            return len(self.clients)
+
+    def submit(self, job):
+        self.q.put(job)
+        return job
+
+    def close(self):
+        self.stopping = True
+        self.q.put(None)
+        self.worker.join(timeout=30)
+
+    # ---- worker
+    def _fail(self, job, exc):
+        job.error = f"{type(exc).__name__}: {exc}"
+        logger.error("request of slot %d failed: %s", job.slot, job.error)  # what handler.py:88-89 does
+        if self.error_replies:
+            try:
+                job.reply(encode_error_response(job.error))
+            except Exception:  # the socket may be gone
+                pass
+        job.done.set()
+
+    def _run_brush(self, job):
+        try:
+            m = self.model
+            m.set_brush(job.payload, slot=job.slot)                                   # handler.py:94
+            mask = preview_mask(m.resolution()).to(m.device())                       # :95
+            context = torch.cat([m.slot_image(job.slot).to(m.device()), mask], dim=1)  # :97
+            result = m.generate(context, slots=[job.slot], **job.settings).cpu()     # :98
+            job.reply(sio.encode_generated_response(sio.RequestType.RETURN_PREVIEW, torch_to_np(result[0])))  # :100-101
+            job.done.set()
+        except Exception as e:
+            self._fail(job, e)
+
+    def _run_stamps(self, jobs):
+        try:
+            m = self.model
+            canvas = torch.stack([j.payload for j in jobs]).to(m.device())            # handler.py:106, batched
+            result = m.generate(canvas, slots=[j.slot for j in jobs], **jobs[0].settings).cpu()  # :107
+            self.batch_sizes.append(len(jobs))
+        except Exception as e:
+            if len(jobs) == 1:
+                return self._fail(jobs[0], e)
+            for j in jobs:  # one bad canvas must not take the other clients' stamps down: retry them one by one
+                self._run_stamps([j])
+            return
+        for j, img in zip(jobs, result):
+            try:
+                j.reply(sio.encode_generated_response(sio.RequestType.RETURN_STAMP, torch_to_np(img)))  # :109-110
+            except Exception as e:
+                logger.error("reply failed: %s", e)
+            j.done.set()
+
+    def _run(self):
+        while True:
+            job = self.q.get()
+            if job is None or self.stopping:
+                return
+            if job.kind == "brush":
+                self._run_brush(job)
+                continue
+            # gather what else is pending right now (plus a short window for stamps that are about to arrive)
+            pending = [job]
+            held = []
+            try:
+                while len(pending) < self.max_batch:
+                    nxt = self.q.get(timeout=self.window)
+                    if nxt is None:
+                        self.q.put(None)
+                        break
+                    if nxt.kind == "stamp" and _settings_key(nxt.settings) == _settings_key(job.settings):
+                        pending.append(nxt)
+                    else:
+                        held.append(nxt)   # a brush change or other settings: next round, order among those preserved
+                        if nxt.kind == "brush":
+                            break
+            except queue.Empty:
+                pass
+            self._run_stamps(pending)
+            for h in held:
+                if h.kind == "brush":
+                    self._run_brush(h)
+                else:
+                    self.q.put(h)
+
+
+class StampServer:
+    """Front of N replicas.  `on_message(client_id, message, write_message)` is the whole per-connection protocol
+    (handler.py:78-123); `close_client` frees the client's slot."""
+
+    def __init__(self, models, max_batch=8, error_replies=False, gather_window_s=0.002):
+        self.queues = [StampQueue(m, max_batch=max_batch, error_replies=error_replies, gather_window_s=gather_window_s) for m in models]
+        self.route = {}  # client id -> queue index
+        self.error_replies = error_replies
+        self.lock = threading.Lock()
+
+    def _queue_of(self, client_id):
+        with self.lock:
+            if client_id not in self.route:
+                self.route[client_id] = min(range(len(self.queues)), key=lambda i: self.queues[i].load())  # least-loaded replica
+            q = self.queues[self.route[client_id]]
+        return q, q.attach(client_id)
+
+    def close_client(self, client_id):
+        with self.lock:
+            i = self.route.pop(client_id, None)
+        if i is not None:
+            self.queues[i].detach(client_id)
+
+    def close(self):
+        for q in self.queues:
+            q.close()
+
+    def on_message(self, client_id, message, write_message, wait=False):
+        """Decode one websocket message and enqueue the work; the reply is sent from the replica's worker thread through
+        `write_message`.  Returns the job (tests wait on job.done).  Decoding errors are handled like execution errors."""
+        try:
+            if not isinstance(message, (bytes, bytearray, memoryview)):
+                raise NotImplementedError("Json messages not handled")               # handler.py:125-129
+            meta, settings, off = sio.decode_request_metadata(message)                # :116
+            q, slot = self._queue_of(client_id)
+            res = q.model.resolution()
+            if meta["type"] == sio.RequestType.NEW_BRUSH_IMAGE.value:                 # :117-119
+                img = np_to_torch(sio.decode_new_brush_image_request(message, off)["image"])
+                job = _Job("brush", slot, settings, img, write_message)
+            elif meta["type"] == sio.RequestType.NEW_STAMP.value:                     # :120-122
+                canvas = np_to_torch(sio.binary_to_image(message, off))
+                if tuple(canvas.shape) != (4, res, res):
+                    raise ValueError(f"stamp canvas must be {res}x{res} RGBA, got {tuple(canvas.shape)}")
+                job = _Job("stamp", slot, settings, canvas, write_message)
+            else:
+                raise NotImplementedError(f"Unknown binary request type {meta['type']}")  # :123
+        except Exception as e:
+            logger.error("Failed to decode incoming message: %s", e)                  # :88-89
+            if self.error_replies:
+                write_message(encode_error_response(f"{type(e).__name__}: {e}"))
+            return None
+        q.submit(job)
+        if wait:
+            job.done.wait()
+        return job

@@ -71,6 +71,14 @@ int dtp_set_brush(dtp_ctx* ctx, const float* image, int H, int W, float* image_o
 int dtp_set_conditioning(dtp_ctx* ctx, const float* cond, const float* uncond, const float* brush, dtp_stream s);
 int dtp_get_conditioning(dtp_ctx* ctx, float* cond, float* uncond, dtp_stream s);
 
+/* Conditioning slots (the multi-client server row): stamps of DIFFERENT clients -- each with its own brush --
+ * can share one batched dtp_stamp_slots call.  Slot 0 is the brush the single-client entry points above use; the slot
+ * variants take slot in [0, DTP_MAX_SLOTS). */
+#define DTP_MAX_SLOTS 16
+int dtp_set_brush_slot(dtp_ctx* ctx, int slot, const float* image, int H, int W, float* image_out, dtp_stream s);
+int dtp_set_conditioning_slot(dtp_ctx* ctx, int slot, const float* cond, const float* uncond, const float* brush, dtp_stream s);
+int dtp_get_conditioning_slot(dtp_ctx* ctx, int slot, float* cond, float* uncond, dtp_stream s);
+
 typedef struct {
   int steps;        /* settings['steps']        (server_io.py:104) */
   int context_pad;  /* settings['context_pad']  */
@@ -92,6 +100,10 @@ typedef struct {
  * which rebuilds the schedule tables (update_infer_settings, inpaint_pipeline.py:39-50) and waits for the stream once. */
 int dtp_stamp(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const float* latents, const float* vae_eps,
               void* out, int B, dtp_stream s);
+/* The same with one conditioning slot per stamp: slots = host int[B] (NULL = all slot 0).  Stamp b is conditioned on the brush
+ * of slot slots[b] (its conditioning tokens and its hint image, trt_model.py:103-114); everything else is shared. */
+int dtp_stamp_slots(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, const float* latents, const float* vae_eps,
+                    void* out, int B, const int* slots, dtp_stream s);
 
 /* Host-only: the DDIM tables dtp_stamp uses for `steps` inference steps -- timesteps[steps] (descending,
  * +1 offset), alphas_cumprod gathered at those timesteps, and final_alpha_cumprod

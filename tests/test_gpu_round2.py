@@ -293,3 +293,64 @@ def test_weights_from_checkpoint_files_give_identical_stamps(tmp_path, sd):
         m._lib.dtp_destroy(m._h)
         m._h = None
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_multi_brush_batch_matches_the_oracle_per_stamp(env, sd):
+    """f2: one batched call, every stamp conditioned on ITS slot's brush (conditioning tokens + hint image), against the oracle
+    run per stamp with that brush; then slot 1 is redefined and only the stamps that use it change."""
+    from oracle import pipeline
+    m = env["model"]
+    ins = [_inputs(1, R, 1000 + i) for i in range(3)]
+    for slot, (_, brush, cond, uncond, _, _) in zip((0, 1, 5), ins):
+        m.set_conditioning(cond, uncond, brush, slot=slot)
+    canvas = torch.cat([i[0] for i in ins] + [ins[1][0]])
+    lat = torch.cat([i[4] for i in ins] + [ins[2][4]])
+    eps = torch.cat([i[5] for i in ins] + [ins[0][5]], dim=1)
+    slots = [0, 1, 5, 1]
+    st = dict(steps=3, context_pad=7, tg_steps=3, cfg_weight=2.0, tg_weight=1.0)
+    got = m.generate_raw(canvas, latents=lat, vae_eps=eps, slots=slots, **st).cpu()
+    by_slot = {0: ins[0], 1: ins[1], 5: ins[2]}
+    for b, sl in enumerate(slots):
+        _, brush, cond, uncond, _, _ = by_slot[sl]
+        ref = pipeline.generate_raw(env["nets"], brush, cond, uncond, canvas[b:b + 1], lat[b:b + 1], eps[:, b:b + 1], **st)
+        err = (got[b:b + 1] - ref).abs().max().item()
+        print(f"stamp {b} (slot {sl}): {err:.2e}")
+        assert err <= 1e-2
+    again = m.generate_raw(canvas, latents=lat, vae_eps=eps, slots=slots, **st).cpu()
+    assert torch.equal(again, got)
+    m.set_conditioning(ins[0][2], ins[0][3], ins[0][1], slot=1)  # slot 1 now holds brush 0
+    moved = m.generate_raw(canvas, latents=lat, vae_eps=eps, slots=slots, **st).cpu()
+    assert torch.equal(moved[0], got[0]) and torch.equal(moved[2], got[2]) and not torch.equal(moved[1], got[1])
+    from diffusiontexturepainting_amd._lib import DtpError
+    with pytest.raises(DtpError):
+        m.generate_raw(canvas[:1], latents=lat[:1], vae_eps=eps[:, :1], slots=[9], **st)  # slot 9 was never set
+
+
+def test_server_batches_two_real_clients(env):
+    """The serving core on the real operator: two clients with different brushes, stamps in flight together -> one B=2 call;
+    each reply equals the client's own single-stamp result within the stamp tolerance."""
+    from diffusiontexturepainting_amd import server as S, server_io as sio
+    m = env["model"]
+    srv = S.StampServer([m], max_batch=8, error_replies=True, gather_window_s=0.2)
+    rng = np.random.default_rng(3)
+    hdr = sio.encode_inference_settings(steps=3, width=R, context_pad=9, cfg_weight=2.0, tg_weight=1.0, tg_steps=3)
+    out = {"a": [], "b": []}
+    for cid in out:
+        brush = rng.integers(0, 256, size=(R, R + 7, 4), dtype=np.uint8)
+        job = srv.on_message(cid, sio.encode_request_type(sio.RequestType.NEW_BRUSH_IMAGE) + hdr + sio.encode_new_brush_image_request(brush),
+                             out[cid].append)
+        assert job.done.wait(60) and sio.decode_response(out[cid][0])["type"] == sio.RequestType.RETURN_PREVIEW.value
+    canv = {cid: rng.integers(0, 256, size=(R, R, 4), dtype=np.uint8) for cid in out}
+    for c in canv.values():
+        c[..., 3] = np.where(rng.random((R, R)) > 0.5, 255, 0)
+    torch.manual_seed(0)
+    jobs = [srv.on_message(cid, sio.encode_request_type(sio.RequestType.NEW_STAMP) + hdr + sio.image_to_binary(canv[cid]), out[cid].append)
+            for cid in out]
+    assert all(j.done.wait(60) for j in jobs)
+    assert srv.queues[0].batch_sizes[-1] == 2
+    for cid in out:
+        rep = sio.decode_response(out[cid][1])
+        assert rep["type"] == sio.RequestType.RETURN_STAMP.value and rep["image"].shape == (R, R, 3)
+        known = canv[cid][..., 3] == 255
+        assert np.array_equal(rep["image"][known], canv[cid][..., :3][known])  # painted pixels come back bit-exact
+    srv.close()

@@ -1,0 +1,145 @@
+"""The serving core (diffusiontexturepainting_amd/server.py) on CPU with a fake model: handler flow bytes -> bytes
+(trt_inference/handler.py:78-123), batching of concurrent clients' stamps, per-client brush slots, routing over replicas,
+error replies instead of the reference's swallowed exception (handler.py:83-89)."""
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from diffusiontexturepainting_amd import server as S, server_io as sio
+from diffusiontexturepainting_amd.model_base import ConditionalInpainterBase
+
+R = 16
+
+
+class FakeModel(ConditionalInpainterBase):
+    """raw output = the slot's brush colour scaled by cfg_weight/10: makes slot / settings mix-ups visible in the pixels."""
+
+    def __init__(self, delay=0.02, name="gpu0"):
+        super().__init__()
+        self.name, self.delay = name, delay
+        self.brushes, self.calls = {}, []
+
+    def device(self):
+        return torch.device("cpu")
+
+    def resolution(self):
+        return R
+
+    def set_brush(self, image, slot=0):
+        assert image.shape[0] == 3
+        self.brushes[slot] = image.mean(dim=(1, 2)).view(1, 3, 1, 1).expand(1, 3, R, R).clone()
+
+    def slot_image(self, slot):
+        return self.brushes[slot]
+
+    def generate_raw(self, canvas, slots=None, **settings):
+        if any(float(c[:3].max()) > 0.999 and float(c[3].min()) > 0.999 for c in canvas):
+            raise RuntimeError("poisoned canvas")
+        time.sleep(self.delay)
+        slots = slots or [0] * canvas.shape[0]
+        self.calls.append((tuple(slots), float(settings["cfg_weight"])))
+        return torch.cat([self.brushes[s] * float(settings["cfg_weight"]) / 10.0 for s in slots])
+
+    def generate(self, canvas, slots=None, **settings):
+        raw = self.generate_raw(canvas, slots=slots, **settings)
+        a = canvas[:, 3:]
+        return canvas[:, :3] * a + raw * (1 - a)
+
+
+def _brush_msg(colour, cfg=2.0):
+    img = np.zeros((R + 4, R, 4), np.uint8)
+    img[..., :3] = colour
+    hdr = sio.encode_inference_settings(steps=3, width=R, context_pad=5, cfg_weight=cfg, tg_weight=1.0, tg_steps=3)
+    return sio.encode_request_type(sio.RequestType.NEW_BRUSH_IMAGE) + hdr + sio.encode_new_brush_image_request(img)
+
+
+def _stamp_msg(cfg=2.0, alpha=0, rgb=7):
+    canvas = np.full((R, R, 4), rgb, np.uint8)
+    canvas[..., 3] = alpha
+    hdr = sio.encode_inference_settings(steps=3, width=R, context_pad=5, cfg_weight=cfg, tg_weight=1.0, tg_steps=3)
+    return sio.encode_request_type(sio.RequestType.NEW_STAMP) + hdr + sio.image_to_binary(canvas)
+
+
+def test_single_client_flow_bytes_to_bytes():
+    m = FakeModel(delay=0)
+    srv = S.StampServer([m])
+    out = []
+    srv.on_message("c1", _brush_msg((200, 100, 50)), out.append, wait=True)
+    prev = sio.decode_response(out[0])
+    assert prev["type"] == sio.RequestType.RETURN_PREVIEW.value and prev["image"].shape == (R, R, 3)
+    # known quadrant = the brush itself, the rest = raw output (brush * cfg/10), truncated like handler.py:55-56
+    assert all(abs(int(v) - c) <= 1 for v, c in zip(prev["image"][0, 0], (200, 100, 50)))
+    assert all(abs(int(v) - c) <= 1 for v, c in zip(prev["image"][R - 1, R - 1], (40, 20, 10)))
+    srv.on_message("c1", _stamp_msg(cfg=5.0), out.append, wait=True)
+    st = sio.decode_response(out[1])
+    assert st["type"] == sio.RequestType.RETURN_STAMP.value and all(abs(int(v) - c) <= 1 for v, c in zip(st["image"][3, 3], (100, 50, 25)))
+    srv.close()
+
+
+def test_concurrent_clients_are_batched_with_their_own_brushes():
+    m = FakeModel(delay=0.05)
+    srv = S.StampServer([m], max_batch=8, gather_window_s=0.05)
+    colours = {f"c{i}": (10 * i + 10, 20, 200 - 10 * i) for i in range(6)}
+    replies = {k: [] for k in colours}
+    for k, col in colours.items():
+        srv.on_message(k, _brush_msg(col), replies[k].append, wait=True)
+    m.calls.clear()
+    jobs = [srv.on_message(k, _stamp_msg(cfg=10.0), replies[k].append) for k in colours]     # all in flight at once
+    other = srv.on_message("c0", _stamp_msg(cfg=5.0), replies["c0"].append)                    # different settings: own call
+    for j in jobs + [other]:
+        assert j.done.wait(10)
+    assert max(len(c[0]) for c in m.calls) >= 4, m.calls           # several clients shared one call ...
+    assert all(len({cfg}) == 1 for _, cfg in m.calls) and any(cfg == 5.0 and len(sl) == 1 for sl, cfg in m.calls)
+    for k, col in colours.items():                                  # ... and each got ITS brush back (cfg 10 -> brush colour)
+        img = sio.decode_response(replies[k][1])["image"]
+        assert all(0 <= c - int(v) <= 1 for v, c in zip(img[5, 5], col)), (k, img[5, 5])  # (x * 255) truncation may lose one level
+    assert all(abs(int(v) - c // 2) <= 1 for v, c in zip(sio.decode_response(replies["c0"][2])["image"][5, 5], colours["c0"]))
+    srv.close()
+
+
+def test_error_frames_and_isolation():
+    m = FakeModel(delay=0.02)
+    srv = S.StampServer([m], error_replies=True, gather_window_s=0.05)
+    a, b = [], []
+    srv.on_message("a", _brush_msg((50, 60, 70)), a.append, wait=True)
+    srv.on_message("b", _brush_msg((90, 80, 70)), b.append, wait=True)
+    bad = srv.on_message("a", _stamp_msg(cfg=10.0, alpha=255, rgb=255), a.append)   # the fake model raises on this canvas
+    good = srv.on_message("b", _stamp_msg(cfg=10.0), b.append)
+    assert bad.done.wait(10) and good.done.wait(10)
+    assert a[1][0] == S.RETURN_ERROR and "poisoned" in S.decode_error_response(a[1])
+    assert sio.decode_response(b[1])["type"] == sio.RequestType.RETURN_STAMP.value   # the batch mate still got its stamp
+    # decode-level failures: unknown type, JSON message, wrong canvas size
+    srv.on_message("a", bytes([9]) + _stamp_msg()[1:], a.append)
+    srv.on_message("a", "{}", a.append)
+    small = np.zeros((R // 2, R // 2, 4), np.uint8)
+    hdr = sio.encode_inference_settings(steps=3, width=R)
+    srv.on_message("a", sio.encode_request_type(sio.RequestType.NEW_STAMP) + hdr + sio.image_to_binary(small), a.append)
+    assert [f[0] for f in a[2:5]] == [S.RETURN_ERROR] * 3 and "RGBA" in S.decode_error_response(a[4])
+    srv.close()
+    # default (reference behaviour): log and send nothing
+    quiet = S.StampServer([FakeModel(delay=0)])
+    out = []
+    quiet.on_message("x", "{}", out.append)
+    assert out == []
+    quiet.close()
+
+
+def test_clients_are_routed_to_the_least_loaded_replica_and_stay_there():
+    m0, m1 = FakeModel(delay=0, name="gpu0"), FakeModel(delay=0, name="gpu1")
+    srv = S.StampServer([m0, m1])
+    sink = []
+    for i in range(6):
+        srv.on_message(f"c{i}", _brush_msg((i, i, i)), sink.append, wait=True)
+    assert len(m0.brushes) == 3 and len(m1.brushes) == 3          # spread evenly ...
+    before = (len(m0.calls), len(m1.calls))
+    srv.on_message("c1", _stamp_msg(), sink.append, wait=True)
+    srv.on_message("c1", _stamp_msg(), sink.append, wait=True)
+    after = (len(m0.calls), len(m1.calls))
+    assert sorted(x - y for x, y in zip(after, before)) == [0, 2]  # ... and a client sticks to its replica (its brush lives there)
+    srv.close_client("c1")
+    srv.on_message("new", _brush_msg((1, 2, 3)), sink.append, wait=True)
+    assert sorted([srv.queues[0].load(), srv.queues[1].load()]) == [3, 3]  # the freed place was reused
+    srv.close()
