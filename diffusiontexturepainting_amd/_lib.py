@@ -86,6 +86,7 @@ SYMBOLS = {
     "dtp_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
     "dtp_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp]),
     "dtp_op_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
+    "dtp_op_attention_fp8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _f, _f, _vp]),
     "dtp_op_dilate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 

@@ -170,6 +170,18 @@ int dtp_op_attention(const void* Q, const void* K, const void* V, void* O, int l
   return dtp_launch_attention(p, (hipStream_t)s);
 }
 
+int dtp_op_attention_fp8(const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo, int B, int H,
+                         int Sq, int Skv, int D, int64_t qbs, int64_t kbs, int64_t vbs, int64_t obs, float scale, float q_scale,
+                         float v_scale, dtp_stream s) {
+  AttnParams p;
+  p.Q = (const f16*)Q; p.K = (const f16*)K; p.V = (const f16*)V; p.O = (f16*)O;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.D = D;
+  p.qbs = qbs; p.kbs = kbs; p.vbs = vbs; p.obs = obs;
+  p.scale = scale;
+  return dtp_launch_attention_fp8(p, q_scale, v_scale, (hipStream_t)s);
+}
+
 int dtp_op_softmax_rows(const void* x, int ldx, void* y, int ldy, int rows, int cols, float scale, dtp_stream s) {
   return dtp_launch_softmax_rows((const f16*)x, ldx, (f16*)y, ldy, rows, cols, scale, (hipStream_t)s);
 }

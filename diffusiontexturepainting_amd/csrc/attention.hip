@@ -101,15 +101,13 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1))) void atte
   // keys beyond Skv (last tile of a ragged sequence) read the clamped last row -- their scores are masked to NEG below, so
   // p = 0 multiplies a finite V.  The padding columns of the K tile (D <= c*8 < DP, incl. the SHIFT ones column) are
   // written once before the loop.
-  // whole waves past the end of the chunk list skip their loads (64 * NCH and 32 * NCH are multiples of 64: wave-uniform)
-  const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
   const f16* ksrc[KIT]; bool kval[KIT]; int kkv[KIT];
 #pragma unroll
   for (int it = 0; it < KIT; ++it) {
     const int idx = tid + it * 256;
     const int kv = idx / NCH, c = idx - kv * NCH;
     kval[it] = (idx < 64 * NCH) && (c * 8 < D);
-    kkv[it] = min(kv, 63);
+    kkv[it] = kval[it] ? kv : 0;   // threads without a chunk all read the tile's first 16 bytes (one line, broadcast)
     ksrc[it] = Kb + (kval[it] ? c * 8 : 0);
   }
   const f16* vsrc[VIT]; bool vval[VIT]; int vkv[VIT];
@@ -118,32 +116,28 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1))) void atte
     const int idx = tid + it * 256;
     const int c = idx >> 5, pr = idx & 31;
     vval[it] = (c < NCH) && (c * 8 < D);
-    vkv[it] = 2 * pr;
+    vkv[it] = vval[it] ? 2 * pr : 0;
     vsrc[it] = Vb + (vval[it] ? c * 8 : 0);
   }
   auto prefetch = [&](int kv0) {
     if (kv0 + 64 <= p.Skv) {  // full tile (wave-uniform)
 #pragma unroll
-      for (int it = 0; it < KIT; ++it)
-        if (wbase + it * 256 < 64 * NCH) kreg[it] = *(const f16x8*)(ksrc[it] + (size_t)(kv0 + kkv[it]) * p.ldk);
+      for (int it = 0; it < KIT; ++it) kreg[it] = *(const f16x8*)(ksrc[it] + (size_t)(kv0 + kkv[it]) * p.ldk);
 #pragma unroll
-      for (int it = 0; it < VIT; ++it)
-        if (wbase + it * 256 < 32 * NCH) {
-          const f16* v0 = vsrc[it] + (size_t)(kv0 + vkv[it]) * p.ldv;
-          vreg[it][0] = *(const f16x8*)v0;
-          vreg[it][1] = *(const f16x8*)(v0 + p.ldv);
-        }
+      for (int it = 0; it < VIT; ++it) {
+        const f16* v0 = vsrc[it] + (size_t)(kv0 + vkv[it]) * p.ldv;
+        vreg[it][0] = *(const f16x8*)v0;
+        vreg[it][1] = *(const f16x8*)(v0 + p.ldv);
+      }
     } else {
       const int last = p.Skv - 1;
 #pragma unroll
-      for (int it = 0; it < KIT; ++it)
-        if (wbase + it * 256 < 64 * NCH) kreg[it] = *(const f16x8*)(ksrc[it] + (size_t)min(kv0 + kkv[it], last) * p.ldk);
+      for (int it = 0; it < KIT; ++it) kreg[it] = *(const f16x8*)(ksrc[it] + (size_t)min(kv0 + kkv[it], last) * p.ldk);
 #pragma unroll
-      for (int it = 0; it < VIT; ++it)
-        if (wbase + it * 256 < 32 * NCH) {
-          vreg[it][0] = *(const f16x8*)(vsrc[it] + (size_t)min(kv0 + vkv[it], last) * p.ldv);
-          vreg[it][1] = *(const f16x8*)(vsrc[it] + (size_t)min(kv0 + vkv[it] + 1, last) * p.ldv);
-        }
+      for (int it = 0; it < VIT; ++it) {
+        vreg[it][0] = *(const f16x8*)(vsrc[it] + (size_t)min(kv0 + vkv[it], last) * p.ldv);
+        vreg[it][1] = *(const f16x8*)(vsrc[it] + (size_t)min(kv0 + vkv[it] + 1, last) * p.ldv);
+      }
     }
   };
   auto stage = [&](int buf) {

@@ -153,6 +153,8 @@ struct AttnParams {
   float scale;
 };
 int dtp_launch_attention(const AttnParams& p, hipStream_t s);
+// attention_fp8.hip: the same contraction on the fp8 (e4m3) MX MFMA; q_scale / v_scale = per-tensor scales (powers of two)
+int dtp_launch_attention_fp8(const AttnParams& p, float q_scale, float v_scale, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise / layout (elementwise.hip)
 int dtp_launch_concat_channels(const f16* a, int lda, int Ca, const f16* b, int ldb, int Cb, f16* y, int ldy, long long rows,

@@ -226,6 +226,7 @@ struct Ctx {
   IencBufs ienc_bufs;
   int* finite_flag = nullptr;     // device: set to 1 by the post-loop finiteness check ("check_finite" option)
   bool check_finite = false;
+  bool fp8_attention = false;     // UNet self-attention on the fp8 MX MFMA (BASELINE configs[4]); fixed once a UNet program exists
   bool finite_pending = false;    // the last stamp ran the check; dtp_last_stamp_finite reads the flag
   std::map<long long, StampGraph> graphs;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -645,8 +645,9 @@ int Builder::attention(const T& q, const T& k, const T& v, int heads, int Sq, in
   a.B = Bn; a.H = heads; a.Sq = Sq; a.Skv = Skv; a.D = q.C / heads;
   a.qbs = (long long)Sq * q.ld; a.kbs = (long long)Skv * k.ld; a.vbs = (long long)Skv * v.ld; a.obs = (long long)Sq * o.ld;
   a.scale = 1.0f / sqrtf((float)a.D);
+  const bool fp8 = c->fp8_attention && (a.D % 64) != 0 && a.D <= 184 && Skv >= 64;  // the brush encoder's tiny attentions stay f16
   push(PK_ATTN, 4.0 * Bn * heads * (double)Sq * Skv * a.D, 2.0 * Bn * q.C * (2.0 * Sq + 2.0 * Skv),
-       [=](hipStream_t s, int) { return dtp_launch_attention(a, s); },
+       [=](hipStream_t s, int) { return fp8 ? dtp_launch_attention_fp8(a, 1.0f, 1.0f, s) : dtp_launch_attention(a, s); },
        "attn B=" + std::to_string(Bn) + " Sq=" + std::to_string(Sq) + " Skv=" + std::to_string(Skv) + " D=" + std::to_string(a.D));
   return DTP_OK;
 }

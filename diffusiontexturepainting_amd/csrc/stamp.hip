@@ -558,6 +558,14 @@ int dtp_set_option(dtp_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "use_graph")) { c->use_graph = value != 0; return DTP_OK; }
   if (!strcmp(name, "autotune")) { c->autotune = value != 0; return DTP_OK; }
   if (!strcmp(name, "check_finite")) { c->check_finite = value != 0; return DTP_OK; }
+  if (!strcmp(name, "fp8_attention")) {
+    if (!c->unet_progs.empty() && c->fp8_attention != (value != 0)) {
+      dtp_set_error("dtp_set_option: fp8_attention must be chosen before the first UNet program is built");
+      return DTP_ERR_STATE;
+    }
+    c->fp8_attention = value != 0;
+    return DTP_OK;
+  }
   dtp_set_error("dtp_set_option: unknown option '%s'", name);
   return DTP_ERR_ARG;
 }

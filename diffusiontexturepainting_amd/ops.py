@@ -162,6 +162,20 @@ def attention(q, k, v, heads, scale=None):
     return o
 
 
+def attention_fp8(q, k, v, heads, scale=None, q_scale=1.0, v_scale=1.0):
+    """attention() with both contractions on the fp8 (e4m3) MX MFMA; tensors stay f16 in memory."""
+    lib = _lib.load()
+    b, sq, c = q.shape
+    skv = k.shape[1]
+    d = c // heads
+    o = torch.empty(b, sq, c, dtype=torch.float16, device=q.device)
+    scale = scale if scale is not None else d ** -0.5
+    check(lib.dtp_op_attention_fp8(ptr(q), ptr(k), ptr(v), ptr(o), q.stride(1), k.stride(1), v.stride(1), o.stride(1), b, heads,
+                                   sq, skv, d, q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, q_scale, v_scale, _stream()),
+          "attention_fp8")
+    return o
+
+
 def softmax_rows(x, scale=1.0):
     lib = _lib.load()
     rows, cols = x.shape

@@ -135,7 +135,8 @@ int dtp_profile_dump(dtp_ctx* ctx, const char* path);
 /* options: "use_graph" (default 1): replay captured hipGraphs; "autotune" (default 1): time tile x split-K candidates per
  * contraction shape when a launch program is built; "check_finite" (default 0): after every stamp ONE reduction over the
  * final latents and the decoded image looks for NaN/inf (the reference asserts `not isnan` after every step with a host
- * sync each, stable_diffusion_pipeline.py:415) -- read the verdict with dtp_last_stamp_finite. */
+ * sync each, stable_diffusion_pipeline.py:415) -- read the verdict with dtp_last_stamp_finite; "fp8_attention" (default 0): the
+ * UNet's self-attention runs on the fp8 MX MFMA (BASELINE configs[4]; choose before the first stamp). */
 int dtp_set_option(dtp_ctx* ctx, const char* name, int value);
 /* *finite = 1 if the last stamp (run with "check_finite" on) produced only finite values, 0 otherwise.  Blocks until that
  * stamp has finished; DTP_ERR_STATE if the option was off. */
@@ -194,6 +195,12 @@ int dtp_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamm
                      float eps, dtp_stream s);
 int dtp_op_attention(const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo, int B, int H,
                      int Sq, int Skv, int D, int64_t qbs, int64_t kbs, int64_t vbs, int64_t obs, float scale, dtp_stream s);
+/* The same attention with both contractions on the fp8 (OCP e4m3) block-scaled MFMA (BASELINE configs[4]): q / k / v / o stay f16 in
+ * memory, tiles are quantised on their way into LDS.  q_scale, v_scale: per-tensor scales (powers of two; Q is stored as
+ * Q*q_scale and K as K/q_scale so the scores are unchanged, V as V/v_scale).  D %% 8 == 0, D %% 64 != 0, D <= 184. */
+int dtp_op_attention_fp8(const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo, int B, int H,
+                         int Sq, int Skv, int D, int64_t qbs, int64_t kbs, int64_t vbs, int64_t obs, float scale, float q_scale,
+                         float v_scale, dtp_stream s);
 int dtp_op_softmax_rows(const void* x, int ldx, void* y, int ldy, int rows, int cols, float scale, dtp_stream s);
 /* kornia.morphology.dilation(alpha, ones(pad,pad)) of add_extra_context (handler.py:28-29) as the stamp runs it: canvas f32
  * [B,4,R,R] (the alpha plane is read), tmp / out f32 [B,R,R]; window rows/cols [i - pad/2, i + pad - pad/2 - 1], clipped */

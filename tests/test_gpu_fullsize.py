@@ -124,3 +124,27 @@ def test_256_20steps_matches_cpu_oracle(weights):
     err = (got.cpu() - ref).abs().max().item()
     print("256^2 / 20 steps: max abs pixel error", err, "stage ms", m.stage_times_ms())
     assert err <= 1e-2 and m.stamp_info()["unet_evals"] == 19
+
+
+FP8_PIXEL_TOL = 3e-2  # BASELINE configs[4]: fp8 (e4m3) attention operands cost more than the 1e-2 of the fp16 path
+
+
+def test_config4_256_8steps_fp8_attention(weights):
+    """configs[4]: 256 x 256, 8 DDIM steps with the UNet's self-attention on the fp8 MX MFMA, against the fp32 CPU oracle.
+    Stated tolerance: max-abs pixel error <= 3e-2 (the fp16 path of the same stamp is gated at 1e-2 and measures ~2e-3)."""
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    from oracle import pipeline
+    canvas, brush, cond, uncond, lat, eps = _inputs(1, 256, 400)
+    st = dict(steps=8, context_pad=150, tg_steps=8, cfg_weight=2.0, tg_weight=1.0)
+    ref = pipeline.generate_raw(weights[1], brush, cond, uncond, canvas, lat, eps, **st)
+    errs = {}
+    for fp8 in (True, False):
+        m = MI355ConditionalInpainter(256, device=0, weights=weights[0], max_batch=1, fp8_attention=fp8)
+        m.set_conditioning(cond, uncond, brush)
+        got = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
+        torch.cuda.synchronize()
+        errs[fp8] = (got.cpu() - ref).abs().max().item()
+        print(f"256^2 / 8 steps, fp8_attention={fp8}: max abs pixel error {errs[fp8]:.2e}, stage ms {m.stage_times_ms()}")
+        assert torch.isfinite(got).all() and m.stamp_info()["unet_evals"] == 7
+    assert errs[False] <= 1e-2 and errs[True] <= FP8_PIXEL_TOL
+    assert errs[True] != errs[False]  # the option really switched the kernels

@@ -62,7 +62,8 @@ def attn_suite():
         v = torch.randn(b, skv, c, device="cuda", dtype=torch.float16)
         t = timeit(lambda: ops.attention(q, k, v, heads), iters=10)
         fl = 4.0 * b * heads * s * skv * d
-        print(f"attn B={b:2d} Sq={s:4d} Skv={skv:4d} d={d:3d}: {fl/t/1e12:6.1f} TF ({t*1e6:8.1f} us)", flush=True)
+        t8 = timeit(lambda: ops.attention_fp8(q, k, v, heads), iters=10) if hasattr(ops, "attention_fp8") and skv >= 64 else float("nan")
+        print(f"attn B={b:2d} Sq={s:4d} Skv={skv:4d} d={d:3d}: {fl/t/1e12:6.1f} TF ({t*1e6:8.1f} us)   fp8: {fl/t8/1e12:6.1f} TF ({t8*1e6:8.1f} us)", flush=True)
 
 
 def norm_suite():
