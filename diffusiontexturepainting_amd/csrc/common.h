@@ -93,6 +93,7 @@ enum {
   GF_ROWSTATS = 2048,// also emit per-row (sum, sum of squares) of the fp16 output, one partial per N tile -> st_out
   GF_SOFTMAX16 = 4096,// epilogue: softmax over each aligned group of 16 output columns (first sm_valid of them; the rest -> 0)
   GF_MFAST = 1 << 20,// internal: tile_m varies fastest (neighbouring workgroups share the W panel)
+  GF_NOREDUCE = 1 << 21,// internal: a split launch leaves its fp32 slabs for the consumer (fused reduce + GroupNorm)
 };
 
 struct GemmParams {
@@ -139,6 +140,12 @@ void dtp_gemm_pick(GemmParams& p, int* tile, int num_cu);  // sets splits/kb_per
 int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, float* stats_ws,
                          int B, int HW, int C, int groups, float eps, int silu, hipStream_t s);
 size_t dtp_groupnorm_ws_bytes(int B, int HW, int C, int groups);
+// split-K reduce (+ bias, + residual) of a conv output fused with the GroupNorm (+SiLU) that consumes it: writes the fp16 conv
+// output c_out AND the normalised tensor y in one launch (HW <= 256)
+bool dtp_reduce_groupnorm_supported(int HW, int C, int groups);
+int dtp_launch_reduce_groupnorm(const float* part, int splits, long long slab, int ldp, const float* bias, const f16* R, int ldr,
+                                f16* c_out, int ldc, f16* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
+                                int groups, float eps, int silu, hipStream_t s);
 int dtp_launch_layernorm(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, int rows, int C,
                          float eps, hipStream_t s);
 int dtp_launch_softmax_rows(const f16* x, int ldx, f16* y, int ldy, int rows, int cols, float scale, hipStream_t s);

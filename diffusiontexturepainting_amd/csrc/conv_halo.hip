@@ -351,6 +351,6 @@ int dtp_launch_conv_halo(const GemmParams& p, int variant, hipStream_t s) {
     default: dtp_set_error("conv_halo: bad variant %d", variant); return DTP_ERR_ARG;
   }
   if (rc != DTP_OK) { dtp_set_error("conv_halo launch failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
-  if (p.splits > 1) return dtp_launch_splitk_reduce(p, s);
+  if (p.splits > 1 && !(p.flags & GF_NOREDUCE)) return dtp_launch_splitk_reduce(p, s);
   return DTP_OK;
 }

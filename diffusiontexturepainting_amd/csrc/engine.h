@@ -54,8 +54,19 @@ struct ProfRec {
   hipEvent_t e0, e1;
   const char* label;  // owned by the closure's std::string (lives as long as the program)
 };
+// the split-K GEMM pushed last (if nothing was pushed after it): a GroupNorm consuming its output folds the reduce in
+struct LastGemm {
+  bool valid = false;
+  GemmParams p;
+  int tile = 0, bias_step_off = -1;
+  size_t op_index = 0;
+  int kind = 0;
+  double flops = 0, bytes = 0;
+  std::string label;
+};
 struct Prog {
   std::vector<Op> ops;
+  LastGemm last_gemm;
   int run(hipStream_t s, int step) const {
     for (const Op& o : ops) RC(o(s, step));
     return DTP_OK;
@@ -226,6 +237,7 @@ struct Ctx {
   IencBufs ienc_bufs;
   int* finite_flag = nullptr;     // device: set to 1 by the post-loop finiteness check ("check_finite" option)
   bool check_finite = false;
+  bool fuse_reduce_gn = true;     // fold a split-K conv's reduce into the GroupNorm that consumes it ($DTP_NO_FUSE_REDUCE_GN=1: off, A/B)
   bool fp8_attention = false;     // UNet self-attention on the fp8 MX MFMA (BASELINE configs[4]); fixed once a UNet program exists
   bool finite_pending = false;    // the last stamp ran the check; dtp_last_stamp_finite reads the flag
   std::map<long long, StampGraph> graphs;

@@ -10,6 +10,8 @@
 #include <algorithm>
 
 static size_t up_to(size_t x, size_t m) { return (x + m - 1) / m * m; }
+static Op make_gemm_op(Ctx* c, GemmParams p, int tile, int bias_step_off);
+void prog_push(Ctx* c, Prog* prog, int kind, double flops, double bytes, Op fn, const std::string& label);
 
 // ---------------------------------------------------------------- memory
 int ctx_arena_alloc(Ctx* c, size_t bytes, void** out) {
@@ -298,6 +300,7 @@ int ensure_ws(Ctx* c) {
 
 // ---------------------------------------------------------------- builder
 void prog_push(Ctx* c, Prog* prog, int kind, double flops, double bytes, Op fn, const std::string& label) {
+  prog->last_gemm.valid = false;
   prog->ops.push_back([=](hipStream_t s, int step) -> int {
     if (!c->profile) return fn(s, step);
     ProfRec r;
@@ -330,6 +333,25 @@ int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
   cc->ws_need = std::max(cc->ws_need, dtp_groupnorm_ws_bytes(x.B, x.H * x.W, x.C, 32));
   const T xx = x, yy = y;
   const NormW nn = n;
+  // The producer was a split-K conv whose reduce has not run yet: sum its slabs here (writes x AND y, one launch fewer)
+  const LastGemm lg = prog->last_gemm;
+  const int keep = GF_BIAS | GF_RESID | GF_CONV3 | GF_UPS2 | GF_MFAST;
+  if (cc->fuse_reduce_gn && lg.valid && lg.p.splits > 1 && (f16*)lg.p.C == x.p && lg.p.ldc == x.ld && lg.p.M == (int)x.rows() && lg.p.N == x.C &&
+      !(lg.p.flags & ~keep) && lg.p.batch <= 1 && dtp_reduce_groupnorm_supported(x.H * x.W, x.C, 32)) {
+    GemmParams gp = lg.p;
+    gp.flags |= GF_NOREDUCE;
+    prog->ops[lg.op_index] = Op();  // rebuilt below through the profiling wrapper
+    prog->ops.pop_back();
+    prog_push(cc, prog, lg.kind, lg.flops, lg.bytes, make_gemm_op(cc, gp, lg.tile, lg.bias_step_off), lg.label + " (reduce in gn)");
+    const int bso = lg.bias_step_off;
+    const bool has_bias = (gp.flags & GF_BIAS) != 0;
+    push(PK_GN, 0.0, 4.0 * (double)xx.rows() * xx.C, [=](hipStream_t s, int step) {
+      const float* bias = !has_bias ? nullptr : (bso >= 0 ? cc->temb_table + (size_t)step * cc->unet.temb_total + bso : gp.bias);
+      return dtp_launch_reduce_groupnorm(cc->ws, gp.splits, (long long)gp.M * gp.N, gp.N, bias, (gp.flags & GF_RESID) ? gp.R : nullptr, gp.ldr,
+                                         xx.p, xx.ld, yy.p, yy.ld, nn.g, nn.b, xx.B, xx.H * xx.W, xx.C, 32, eps, silu ? 1 : 0, s);
+    }, "reduce+gn B=" + std::to_string(x.B) + " HW=" + std::to_string(x.H * x.W) + " C=" + std::to_string(x.C) + " splits=" + std::to_string(gp.splits));
+    return DTP_OK;
+  }
   push(PK_GN, 0.0, 4.0 * (double)xx.rows() * xx.C, [=](hipStream_t s, int) {
     return dtp_launch_groupnorm(xx.p, xx.ld, yy.p, yy.ld, nn.g, nn.b, cc->ws, xx.B, xx.H * xx.W, xx.C, 32, eps, silu ? 1 : 0, s);
   }, "gn B=" + std::to_string(x.B) + " HW=" + std::to_string(x.H * x.W) + " C=" + std::to_string(x.C));
@@ -540,6 +562,16 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   return DTP_OK;
 }
 
+static Op make_gemm_op(Ctx* c, GemmParams p, int tile, int bias_step_off) {
+  return [=](hipStream_t s, int step) -> int {
+    GemmParams q = p;
+    q.part = c->ws;
+    if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;
+    if (tile >= 12 && tile < 16) { q.W = q.Wcb; return dtp_launch_conv_halo(q, tile - 12, s); }
+    return dtp_launch_gemm(q, tile, s);
+  };
+}
+
 int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg, RowStats* emit) {
   int tile = 0;
   dtp_gemm_pick(p, &tile, c->num_cu);
@@ -562,13 +594,14 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
            p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? " geglu" : "", p.stride == 2 ? " s2" : "",
            p.batch > 1 ? (" x" + std::to_string(p.batch)).c_str() : "");
-  prog_push(c, prog, tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile, 2.0 * nb * p.M * (double)p.N * k_alg, bytes, [=](hipStream_t s, int step) {
-    GemmParams q = p;
-    q.part = c->ws;
-    if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;
-    if (tile >= 12 && tile < 16) { q.W = q.Wcb; return dtp_launch_conv_halo(q, tile - 12, s); }
-    return dtp_launch_gemm(q, tile, s);
-  }, lab);
+  const int kind = tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
+  const double flops = 2.0 * nb * p.M * (double)p.N * k_alg;
+  prog_push(c, prog, kind, flops, bytes, make_gemm_op(c, p, tile, bias_step_off), lab);
+  if (p.splits > 1) {  // a GroupNorm pushed next may take over the reduce (Builder::gn)
+    LastGemm& lg = prog->last_gemm;
+    lg.valid = true; lg.p = p; lg.tile = tile; lg.bias_step_off = bias_step_off; lg.op_index = prog->ops.size() - 1;
+    lg.kind = kind; lg.flops = flops; lg.bytes = bytes; lg.label = lab;
+  }
   return DTP_OK;
 }
 
@@ -698,6 +731,7 @@ int dtp_create(int device, int resolution, int max_batch, dtp_ctx** out) {
   c->zero = (f16*)z;
   for (int i = 0; i < 4; ++i) HIP_CHECK(hipEventCreate(&c->ev[i]));
   tune_cache_load(c);
+  if (const char* e = getenv("DTP_NO_FUSE_REDUCE_GN")) c->fuse_reduce_gn = !(e[0] && e[0] != '0');
   *out = (dtp_ctx*)c;
   return DTP_OK;
 }

@@ -647,7 +647,7 @@ int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
   FOR_ALL_VARIANTS(DISPATCH)
 #undef DISPATCH
   if (rc != DTP_OK) { dtp_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
-  if (p.splits > 1) return dtp_launch_splitk_reduce(p, s);
+  if (p.splits > 1 && !(p.flags & GF_NOREDUCE)) return dtp_launch_splitk_reduce(p, s);
   return DTP_OK;
 }
 

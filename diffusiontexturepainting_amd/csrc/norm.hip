@@ -204,6 +204,110 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const f16* __restrict__ 
   }
 }
 
+// Split-K reduce + GroupNorm in ONE launch (small feature maps, HW <= 256): the consumer of a split-K conv is almost always a
+// GroupNorm (conv1 -> norm2, block output -> the next block's norm1), and at UNet levels 2-3 both are pure launch latency.
+// One block per (batch, slab of G groups): every thread sums the fp32 slabs of its (pixel, 8-channel chunk) items, adds bias
+// (+ residual), rounds to fp16 and writes the conv output C (other consumers -- skip connections, residuals -- read it), keeps
+// the rounded values in registers, accumulates the group statistics of exactly those values (same numbers gn_fused_kernel
+// would read back), and after one block-wide reduction normalises (+ SiLU) straight from the registers.
+template <int G, int MAXI>
+__global__ __launch_bounds__(1024) void gn_reduce_fused_kernel(const float* __restrict__ part, int splits, long long slab, int ldp,
+                                                               const float* __restrict__ bias, const f16* __restrict__ R, int ldr,
+                                                               f16* __restrict__ c_out, int ldc, f16* __restrict__ y, int ldy,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int HW,
+                                                               int cpg, int silu, float inv_count, float eps) {
+  __shared__ float red[16][2 * G];
+  __shared__ float st[2 * G];
+  const int nthr = blockDim.x, nwave = blockDim.x >> 6;
+  const int b = blockIdx.y, sl = blockIdx.x;
+  const int cs = sl * G * cpg;
+  const int nchs = (G * cpg) >> 3;
+  const int total = HW * nchs;
+  float s[G], q[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) s[g] = q[g] = 0.f;
+  f16x8 val[MAXI];
+#pragma unroll
+  for (int k = 0; k < MAXI; ++k) {
+    const int i = threadIdx.x + k * nthr;
+    if (i < total) {
+      const int pix = i / nchs, c0 = (i - pix * nchs) * 8;
+      const size_t row = (size_t)b * HW + pix;
+      const float* pp = part + row * ldp + cs + c0;
+      f32x4 a0 = *(const f32x4*)pp, a1 = *(const f32x4*)(pp + 4);
+      for (int z = 1; z < splits; ++z) {
+        const f32x4 t0 = *(const f32x4*)(pp + (size_t)z * slab), t1 = *(const f32x4*)(pp + (size_t)z * slab + 4);
+        a0 += t0; a1 += t1;
+      }
+      if (bias) {
+        const f32x4 b0 = *(const f32x4*)(bias + cs + c0), b1 = *(const f32x4*)(bias + cs + c0 + 4);
+        a0 += b0; a1 += b1;
+      }
+      if (R) {
+        const f16x8 r = *(const f16x8*)(R + row * ldr + cs + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0[e] += (float)r[e]; a1[e] += (float)r[4 + e]; }
+      }
+      f16x8 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { h[e] = (f16)a0[e]; h[4 + e] = (f16)a1[e]; }
+      *(f16x8*)(c_out + row * ldc + cs + c0) = h;
+      val[k] = h;
+      const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
+      float u0 = 0.f, w0 = 0.f, u1 = 0.f, w1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)h[e];
+        if (e < split) { u0 += f; w0 += f * f; } else { u1 += f; w1 += f * f; }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (g == g0) { s[g] += u0; q[g] += w0; }
+        if (g == g0 + 1) { s[g] += u1; q[g] += w1; }
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) { s[g] = wave_sum(s[g]); q[g] = wave_sum(q[g]); }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) { red[threadIdx.x >> 6][2 * g] = s[g]; red[threadIdx.x >> 6][2 * g + 1] = q[g]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    const int g = threadIdx.x;
+    float ss = 0.f, qq = 0.f;
+    for (int w = 0; w < nwave; ++w) { ss += red[w][2 * g]; qq += red[w][2 * g + 1]; }
+    const float mean = ss * inv_count;
+    st[2 * g] = mean;
+    st[2 * g + 1] = rsqrtf(fmaxf(qq * inv_count - mean * mean, 0.f) + eps);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < MAXI; ++k) {
+    const int i = threadIdx.x + k * nthr;
+    if (i < total) {
+      const int pix = i / nchs, c0 = (i - pix * nchs) * 8;
+      const f16x8 v = val[k];
+      const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
+      const int g1 = g0 + 1 < G ? g0 + 1 : g0;
+      const float m0 = st[2 * g0], r0 = st[2 * g0 + 1], m1 = st[2 * g1], r1 = st[2 * g1 + 1];
+      const f32x4 ga0 = *(const f32x4*)(gamma + cs + c0), ga1 = *(const f32x4*)(gamma + cs + c0 + 4);
+      const f32x4 be0 = *(const f32x4*)(beta + cs + c0), be1 = *(const f32x4*)(beta + cs + c0 + 4);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool first = e < split;
+        const float gm = e < 4 ? ga0[e] : ga1[e - 4], bt = e < 4 ? be0[e] : be1[e - 4];
+        float f = ((float)v[e] - (first ? m0 : m1)) * (first ? r0 : r1) * gm + bt;
+        if (silu) f = f / (1.0f + __expf(-f));
+        o[e] = (f16)f;
+      }
+      *(f16x8*)(y + ((size_t)b * HW + pix) * ldy + cs + c0) = o;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- LayerNorm: one wave per row
 template <int MAXCH>  // chunks of 8 per lane
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy,
@@ -321,6 +425,40 @@ int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* ga
   if (bx > cap) bx = cap;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((int)bx, B), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, ws, nchunk, HW, C, cpg,
                      groups, silu, 1.0f / ((float)HW * cpg), eps);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
+
+// Can the split-K reduce of a [B*HW][C] conv output be folded into the GroupNorm that consumes it?  (single-launch GroupNorm
+// shapes only; at most 4 items of 8 channels per thread)
+bool dtp_reduce_groupnorm_supported(int HW, int C, int groups) {
+  if (HW > 256 || (C & 7) || (C % groups) || groups > 64) return false;
+  const int cpg = C / groups;
+  if (cpg < 4 || (cpg < 8 && cpg != 4)) return false;
+  int G = 1;
+  while ((G * cpg) & 7) G *= 2;
+  if (G > 4 || groups % G) return false;
+  const int items = HW * ((G * cpg) >> 3);
+  const int blk = items >= 2048 ? 1024 : (items >= 512 ? 512 : 256);
+  return (items + blk - 1) / blk <= 4;
+}
+
+int dtp_launch_reduce_groupnorm(const float* part, int splits, long long slab, int ldp, const float* bias, const f16* R, int ldr,
+                                f16* c_out, int ldc, f16* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
+                                int groups, float eps, int silu, hipStream_t s) {
+  if (!dtp_reduce_groupnorm_supported(HW, C, groups) || (ldp & 3) || (ldc & 7) || (ldy & 7) || (R && (ldr & 7))) {
+    dtp_set_error("reduce+groupnorm: HW=%d C=%d groups=%d unsupported", HW, C, groups);
+    return DTP_ERR_ARG;
+  }
+  const int cpg = C / groups;
+  int G = 1;
+  while ((G * cpg) & 7) G *= 2;
+  const float inv = 1.0f / ((float)HW * cpg);
+  dim3 grid(groups / G, B);
+  const int items = HW * ((G * cpg) >> 3);
+  const dim3 blk(items >= 2048 ? 1024 : (items >= 512 ? 512 : 256));
+#define DTP_RGN(GG) hipLaunchKernelGGL((gn_reduce_fused_kernel<GG, 4>), grid, blk, 0, s, part, splits, slab, ldp, bias, R, ldr, c_out, ldc, y, ldy, gamma, beta, HW, cpg, silu, inv, eps)
+  if (G == 1) DTP_RGN(1); else if (G == 2) DTP_RGN(2); else DTP_RGN(4);
+#undef DTP_RGN
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
