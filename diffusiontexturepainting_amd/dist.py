@@ -59,6 +59,58 @@ def gather_patches(local, n_total, rank, world, dst=0):
     return torch.cat([b[:n] for b, n in zip(bufs, counts)], dim=0).to(dev)
 
 
+def scatter_stamps(canvases, n_total, rank, world, src=0, device=None):
+    """The inverse of gather_patches (SURVEY.md 8e "optionally a scatter of canvases from rank 0"): rank `src` holds the u8 RGBA
+    canvases [n_total, R, R, 4] of a stamp batch (the wire images, 1 MiB each at 512^2); every rank receives its contiguous shard
+    [hi-lo, R, R, 4].  One collective; shards may be ragged (padded to the largest inside the call).  Other ranks pass
+    `canvases=None` and the per-stamp shape through `device`-side metadata broadcast first."""
+    if world == 1:
+        return canvases
+    meta = [None]
+    if rank == src:
+        meta = [(tuple(canvases.shape[1:]), canvases.dtype)]
+    dist.broadcast_object_list(meta, src=src)
+    shape, dtype = meta[0]
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    gloo_cuda = dist.get_backend() == "gloo" and device is not None and torch.device(device).type == "cuda"
+    work_dev = torch.device("cpu") if (gloo_cuda or device is None) else torch.device(device)
+    out = torch.empty((mx,) + shape, dtype=dtype, device=work_dev)
+    chunks = None
+    if rank == src:
+        chunks = []
+        for lo, hi in sizes:
+            c = canvases[lo:hi].to(work_dev)
+            if hi - lo < mx:
+                c = torch.cat([c, torch.zeros((mx - (hi - lo),) + shape, dtype=dtype, device=work_dev)], dim=0)
+            chunks.append(c.contiguous())
+    dist.scatter(out, scatter_list=chunks, src=src)
+    lo, hi = sizes[rank]
+    out = out[: hi - lo]
+    return out.to(device) if device is not None else out
+
+
+def broadcast_conditioning(cond, uncond, brush, rank, world, src=0, device=None):
+    """Replicate a brush on every rank ("broadcast the [1,14,768] x 2 conditioning + brush image (~3 MB) once per
+    brush"): rank `src` passes the tensors (e.g. model.conditioning + model.image after set_brush), the others pass None and
+    get them; feed the result to model.set_conditioning() on every rank.  Three small broadcasts, once per brush change --
+    never on the per-stamp path."""
+    if world == 1:
+        return cond, uncond, brush
+    meta = [None]
+    if rank == src:
+        meta = [tuple(brush.shape)]
+    dist.broadcast_object_list(meta, src=src)
+    gloo_cuda = dist.get_backend() == "gloo" and device is not None and torch.device(device).type == "cuda"
+    work_dev = torch.device("cpu") if (gloo_cuda or device is None) else torch.device(device)
+    out = []
+    for t, shape in ((cond, (1, 14, 768)), (uncond, (1, 14, 768)), (brush, meta[0])):
+        buf = t.detach().to(work_dev, torch.float32).reshape(shape).contiguous() if rank == src else torch.empty(shape, dtype=torch.float32, device=work_dev)
+        dist.broadcast(buf, src=src)
+        out.append(buf.to(device) if device is not None else buf)
+    return tuple(out)
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

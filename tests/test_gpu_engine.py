@@ -2,7 +2,8 @@
 against the fp32 CPU oracle on identical seeded weights, noise and inputs.
 
 Tolerances (fp16 activations with fp32 accumulation vs an fp32 reference):
-  * one UNet evaluation / VAE pass: max |err| <= 3e-2 * max|ref|   (engine level)
+  * one UNet evaluation / VAE pass: max |err| <= 1e-2 * max|ref|   (engine level; measured 1.0e-3 .. 1.5e-3)
+  * brush encoder (CLIP tower in fp16 + three 4-block stacks): <= 3e-2 * max|ref| (measured 1.5e-3)
   * decoded pixels of a whole stamp: max |err| <= 1e-2 in [0,1] units  (BASELINE.json north_star)
 """
 import numpy as np
@@ -50,7 +51,7 @@ def test_unet_engine_vs_oracle(env, n, t):
     got = env["model"].unet(sample, t, ctx)
     e = rel_err(got, ref)
     print("unet rel err", e)
-    assert e < 3e-2
+    assert e < 1e-2
 
 
 def test_vae_encode_vs_oracle(env):
@@ -62,9 +63,9 @@ def test_vae_encode_vs_oracle(env):
     got = env["model"].vae_encode(img, eps)
     e = rel_err(got, ref)
     print("vae enc rel err", e)
-    assert e < 3e-2
+    assert e < 1e-2
     mean_ref, _ = nets.vae_encode_moments(env["vae"], img)
-    assert rel_err(env["model"].vae_encode(img, None), mean_ref) < 3e-2
+    assert rel_err(env["model"].vae_encode(img, None), mean_ref) < 1e-2
 
 
 def test_vae_decode_vs_oracle(env):
@@ -74,7 +75,7 @@ def test_vae_decode_vs_oracle(env):
     got = env["model"].vae_decode(z)
     e = rel_err(got, ref)
     print("vae dec rel err", e)
-    assert e < 3e-2
+    assert e < 1e-2
 
 
 def _stamp_inputs(b, seed):
