@@ -1,4 +1,4 @@
-"""The bench.py output contract (one JSON line) checked on the committed round-1 measurement, plus the helper that attaches the
+"""The bench.py output contract (one JSON line) checked on the committed round-2 measurement, plus the helper that attaches the
 PMC traffic figure.  CPU only: nothing here launches a kernel."""
 import importlib.util
 import json
@@ -15,7 +15,7 @@ def _bench():
 
 
 def test_committed_bench_line_has_every_contract_field():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_b1.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_b1.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
@@ -32,6 +32,10 @@ def test_committed_bench_line_has_every_contract_field():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["unit"] == "stamps/s"
+    extra = line["extra_configs"]  # driver-witnessed numbers for the other BASELINE configurations, same line
+    assert extra["configs[2]_batch8_512px_20steps"]["stamps_per_s"] > line["value"]
+    assert extra["pixel_max_abs_err_vs_cpu_oracle"]["value"] <= extra["pixel_max_abs_err_vs_cpu_oracle"]["gate"] == 1e-2
+    assert "workload" in line["config"] and "configs[1]" in line["config"]["workload"]
 
 
 def test_pmc_traffic_is_tied_to_the_build_it_was_collected_on():
