@@ -113,11 +113,12 @@ def extra_measurements(model512, sd):
     ms = time_stamps(m256, 1, 256, 8, n=5, warm=2, seed=2200)
     out["configs[4]_workload_256px_8steps_in_f16"] = {"stamps_per_s": 1e3 / ms, "ms_per_stamp": ms, "timed_stamps": 5, "dtype": "f16"}
     del m256
-    m256f8 = MI355ConditionalInpainter(256, device=model512._index, weights=sd, max_batch=1, fp8_attention=True)
+    m256f8 = MI355ConditionalInpainter(256, device=model512._index, weights=sd, max_batch=1, fp8_attention=True, fp8_linear=True)
     ms = time_stamps(m256f8, 1, 256, 8, n=5, warm=2, seed=2200)
-    out["configs[4]_256px_8steps_fp8_attention"] = {
-        "stamps_per_s": 1e3 / ms, "ms_per_stamp": ms, "timed_stamps": 5, "dtype": "f8e4m3 (self-attention QK^T / PV on the MX MFMA) + f16",
-        "note": "latency-bound at batch 1 (192 workgroups per attention launch): the fp8 kernel pays for itself from batch 8 up"}
+    out["configs[4]_256px_8steps_fp8"] = {
+        "stamps_per_s": 1e3 / ms, "ms_per_stamp": ms, "timed_stamps": 5,
+        "dtype": "f8e4m3 (self-attention QK^T / PV and the transformer Linears / 1x1 convs on the MX MFMA) + f16 (3x3 convs, norms, VAE)",
+        "note": "latency-bound at batch 1 (192-workgroup launches, operand conversion on the critical path): fp8 costs time here"}
     del m256f8
     m64 = MI355ConditionalInpainter(64, device=model512._index, weights=sd, max_batch=2)
     canvas, brush, lat, eps = synthetic.make_stamp_batch(2, 64, seed=2300)
@@ -239,7 +240,7 @@ def main():
                       f"{a.res}x{a.res} inpaint stamps/sec @{a.ddim_steps} DDIM steps",
             "value": n_total * a.steps / elapsed, "unit": "stamps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f8e4m3 attention + f16" if model.fp8_attention else "f16", "data": "synthetic",
+            "dtype": ("f8e4m3 attention" + (" + linear" if model.fp8_linear else "") + " + f16") if model.fp8_attention else "f16", "data": "synthetic",
             "config": {"workload": f"{cfg_name}: {a.batch} x {a.res}x{a.res} RGBA stamp(s) per GPU, "
                                    f"{a.ddim_steps} DDIM steps = {a.ddim_steps - 1} UNet evals (reference quirk), 3 guidance branches, "
                                    "cfg 2.0 / tg 1.0 / tg_steps = steps / context_pad 150, SD-1.5-inpaint UNet + LoRA merged + "

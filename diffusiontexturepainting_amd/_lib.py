@@ -29,7 +29,7 @@ PROF_KINDS = [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 
     ["attention_kernel", "groupnorm (gn_stats+gn_apply | gn_fused)", "layernorm_kernel", "concat_kernel / small elementwise",
      "softmax_rows_kernel", "conv_halo_kernel<8, 16, 64>", "conv_halo_kernel<8, 16, 128>", "conv_halo_kernel<8, 8, 64>",
      "conv_halo_kernel<8, 8, 128>", "gemm_kernel<256, 128, 2>", "gemm_kernel<256, 128, 3>", "gemm_kernel<128, 256, 2>",
-     "gemm_kernel<128, 256, 3>", "gemm_wide_kernel<256, 256>", "gemm_wide_kernel<256, 320>"]
+     "gemm_kernel<128, 256, 3>", "gemm_wide_kernel<256, 256>", "gemm_wide_kernel<256, 320>", "gemm_fp8_kernel"]
 
 
 class GemmDesc(C.Structure):
@@ -42,7 +42,8 @@ class GemmDesc(C.Structure):
                 ("A2", C.c_void_p), ("lda2", C.c_int), ("Cin2", C.c_int), ("Wcb", C.c_void_p),
                 ("batch", C.c_int), ("a_bs", C.c_int64), ("w_bs", C.c_int64), ("c_bs", C.c_int64), ("r_bs", C.c_int64),
                 ("bias_bs", C.c_int), ("lns_bs", C.c_int), ("sm_valid", C.c_int),
-                ("st_out", C.c_void_p), ("st_in", C.c_void_p), ("st_parts", C.c_int), ("st_parts_out", C.c_int)]
+                ("st_out", C.c_void_p), ("st_in", C.c_void_p), ("st_parts", C.c_int), ("st_parts_out", C.c_int),
+                ("W8", C.c_void_p), ("ldw8", C.c_int), ("a_scale", C.c_float), ("w_scale", C.c_float)]
 
 
 GF_BIAS, GF_BIAS_M, GF_RESID, GF_GEGLU, GF_GELU, GF_QUICKGELU, GF_OUT_F32, GF_SILU, GF_LNFOLD = 1, 2, 4, 8, 64, 128, 256, 512, 1024
@@ -81,6 +82,7 @@ SYMBOLS = {
     "dtp_op_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dtp_op_pack_conv": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dtp_op_rowsum": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "dtp_op_quantize_w8": (_i, [_vp, _i, _i, _i, _vp, _i, C.POINTER(_f), _vp]),
     "dtp_op_pack_conv_cb": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "dtp_op_groupnorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "dtp_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),

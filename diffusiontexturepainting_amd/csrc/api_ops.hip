@@ -78,6 +78,9 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
   p.batch = d->batch; p.a_bs = d->a_bs; p.w_bs = d->w_bs; p.c_bs = d->c_bs; p.r_bs = d->r_bs;
   p.bias_bs = d->bias_bs; p.lns_bs = d->lns_bs; p.sm_valid = d->sm_valid;
   p.st_out = d->st_out; p.st_in = d->st_in; p.st_parts = d->st_parts;
+  p.W8 = (const unsigned char*)d->W8; p.ldw8 = d->ldw8; p.a_scale = d->a_scale; p.w_scale = d->w_scale;
+  static bool fp8_init = false;
+  if (!fp8_init) { dtp_gemm_fp8_init(); fp8_init = true; }
   if (p.ldw < p.nkb * 64) { dtp_set_error("gemm: ldw=%d smaller than padded K=%d", p.ldw, p.nkb * 64); return DTP_ERR_ARG; }
   int tile = 0;
   dtp_gemm_pick(p, &tile, g_ops.num_cu);
@@ -86,7 +89,8 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
     p.kb_per_split = (p.nkb + d->splits - 1) / d->splits;
     p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
   }
-  if (tile >= 20) { p.splits = 1; p.kb_per_split = p.nkb; }  // the wide tiles are unsplit
+  if (tile >= 20) { p.splits = 1; p.kb_per_split = p.nkb; }  // the wide and fp8 tiles are unsplit
+  if ((tile >= 24) != (p.W8 != nullptr)) { dtp_set_error("gemm: tiles 24..27 and W8 go together"); return DTP_ERR_ARG; }
   if (tile >= 12 && tile < 16) {  // halo-tiled 3x3 conv: split-K counts 64-channel blocks
     if (!d->Wcb) { dtp_set_error("conv_halo: Wcb missing"); return DTP_ERR_ARG; }
     p.W = (const f16*)d->Wcb;
@@ -129,6 +133,11 @@ int dtp_op_pack_linear(const float* w, void* out, int N, int K, int ldw, int geg
     map = g_ops.geglu_map;
   }
   return dtp_launch_pack_linear_weight(w, (f16*)out, N, K, ldw, map, (hipStream_t)s);
+}
+
+int dtp_op_quantize_w8(const void* w, int ldw, int K, int rows, void* out, int ldw8, float* w_scale, dtp_stream s) {
+  if (!w || !out || !w_scale || (ldw8 & 127) || ldw8 < K) { dtp_set_error("quantize_w8: bad argument"); return DTP_ERR_ARG; }
+  return dtp_quantize_weights_fp8((const f16*)w, ldw, K, rows, (unsigned char*)out, ldw8, w_scale, (hipStream_t)s);
 }
 
 int dtp_op_rowsum(const void* w, int ld, int K, float* out, int rows, dtp_stream s) {

@@ -126,6 +126,10 @@ struct GemmParams {
   long long a_bs, w_bs, c_bs, r_bs;
   int bias_bs, lns_bs, st_rows;
   int sm_valid;      // GF_SOFTMAX16: valid columns per group of 16
+  // fp8 (e4m3) variant (gemm_fp8.hip, tile ids 24..27): W8 = per-tensor quantised copy of W, [N_pad][ldw8] bytes (K padded to 128)
+  const unsigned char* W8;
+  int ldw8;
+  float a_scale, w_scale;  // A8 = e4m3(A / a_scale), W8 = e4m3(W / w_scale); powers of two
 };
 
 // tile: shape + 4 * (stages - 2); shape 0 = 128x128, 1 = 128(M)x64(N), 2 = 64x64, 3 = 64(M)x128(N); stages 2..4
@@ -178,6 +182,11 @@ int dtp_launch_matmul_f32(const float* A, const float* B, float* C, int M, int N
 int dtp_launch_expand_kv(const f16* kv, f16* kexp, f16* vexp, int N, int T, int C, int H, float scale, hipStream_t s);
 int dtp_launch_transpose_f16(const f16* src, int lds_, f16* dst, int ldd, int rows, int cols, hipStream_t s);
 int dtp_launch_rowdot_f16(const f16* a, int ld, const float* v, float* out, int rows, int K, hipStream_t s);
+// gemm_fp8.hip: dense GEMM on the fp8 MX MFMA (tile ids 24..27 of dtp_launch_gemm = 128x128 / 128x64 / 64x64 / 64x128)
+bool dtp_gemm_fp8_supported(const GemmParams& p);
+int dtp_launch_gemm_fp8(const GemmParams& p, int tile, hipStream_t s);
+void dtp_gemm_fp8_init();
+int dtp_quantize_weights_fp8(const f16* w, int ldw, int K, int rows, unsigned char* out, int ldw8, float* scale_out, hipStream_t s);
 // gemm_wide.hip: 8-wave wide tiles; variant 0 = 256x256, 1 = 256x320 (tile ids 20 / 21 of dtp_launch_gemm)
 bool dtp_gemm_wide_supported(const GemmParams& p, int variant);
 int dtp_launch_gemm_wide(const GemmParams& p, int variant, hipStream_t s);

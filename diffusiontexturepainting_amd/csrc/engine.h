@@ -29,6 +29,9 @@ struct ConvW {  // 3x3 (taps = 9) or 1x1 (taps = 1) convolution / any Linear (ta
   float* lns = nullptr;  // LayerNorm folded in: row sums of the packed weights (GF_LNFOLD)
   int cout = 0, cin = 0 /* padded */, cin_true = 0, taps = 1, K = 0, ldw = 0;
   int cin2 = 0;  // >0: a 1x1 shortcut conv over cin2 channels is fused as a 10th tap (K = 9*cin + cin2)
+  unsigned char* w8 = nullptr;  // Linear only, option fp8_linear: per-tensor e4m3 copy of `w` [rows][ldw8] (K padded to 128)
+  int ldw8 = 0;
+  float w8_scale = 1.f;
 };
 struct NormW {
   float *g = nullptr, *b = nullptr;
@@ -47,7 +50,7 @@ struct Ctx;
 // A launch program: a flat list of closures bound to statically planned buffers.
 using Op = std::function<int(hipStream_t, int /*step*/)>;
 // profiling classes (dtp_profile_rows): 0-11 = gemm_kernel<BM,BN,NS> variants (id = shape + 4*(NS-2)), then the rest
-enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_BIG0 = 21, PK_WIDE0 = 25, PK_COUNT = 27 };
+enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_BIG0 = 21, PK_WIDE0 = 25, PK_FP8 = 27, PK_COUNT = 28 };
 struct ProfRec {
   int kind;
   double flops, bytes;
@@ -238,6 +241,7 @@ struct Ctx {
   int* finite_flag = nullptr;     // device: set to 1 by the post-loop finiteness check ("check_finite" option)
   bool check_finite = false;
   bool fuse_reduce_gn = true;     // fold a split-K conv's reduce into the GroupNorm that consumes it ($DTP_NO_FUSE_REDUCE_GN=1: off, A/B)
+  bool fp8_linear = false;        // UNet transformer Linears / 1x1 convs on the fp8 MX MFMA (configs[4]); fixed once a UNet program exists
   bool fp8_attention = false;     // UNet self-attention on the fp8 MX MFMA (BASELINE configs[4]); fixed once a UNet program exists
   bool finite_pending = false;    // the last stamp ran the check; dtp_last_stamp_finite reads the flag
   std::map<long long, StampGraph> graphs;
@@ -290,6 +294,7 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
 struct Builder {
   Ctx* c;
   Prog* prog;
+  bool fp8 = false;  // dense Linears pushed through linear() / the transformer tail run on gemm_fp8_kernel when they can
   // append an op; when profiling is on, every launch is bracketed by HIP events on its own stream
   void push(int kind, double flops, double bytes, Op fn, const std::string& label = std::string());
   T alloc(int B, int H, int W, int C);
@@ -315,6 +320,7 @@ int build_vae_dec_prog(Ctx* c, int B, VaeDecProg& p);
 int load_unet_weights(Ctx* c);
 int load_vae_weights(Ctx* c);
 int ensure_ws(Ctx* c);
+int ensure_w8(Ctx* c, ConvW& w);  // build the e4m3 copy of a Linear's packed weights (once)
 void tune_cache_load(Ctx* c);
 void tune_cache_save(Ctx* c);
 int ensure_temb(Ctx* c, const std::vector<float>& timesteps);  // fills temb_table rows 0..n-1

@@ -282,6 +282,16 @@ int load_plain_f16(Ctx* c, const std::string& name, f16** out) {
   return DTP_OK;
 }
 
+int ensure_w8(Ctx* c, ConvW& w) {
+  if (w.w8 || w.taps != 1 || !w.w) return DTP_OK;
+  const size_t rows = up_to(w.cout, 128);
+  w.ldw8 = (int)up_to(w.K, 128);
+  void* p;
+  RC(ctx_arena_alloc(c, rows * (size_t)w.ldw8, &p));  // arena chunks are zero-initialised: padded rows / columns stay 0
+  w.w8 = (unsigned char*)p;
+  return dtp_quantize_weights_fp8(w.w, w.ldw, w.K, (int)rows, w.w8, w.ldw8, &w.w8_scale, 0);
+}
+
 int ensure_ws(Ctx* c) {
   if (c->ws_need <= c->ws_bytes) return DTP_OK;
   HIP_CHECK(hipDeviceSynchronize());
@@ -401,6 +411,8 @@ static bool tune_entry_valid(const GemmParams& p, int tile, int sp) {
   if (halo) return p.Wcb && dtp_conv_halo_supported(p) && p.batch <= 1;
   int bm = 0, bn = 0, ns = 0;
   if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) return false;
+  if (tile >= 24) { GemmParams q = p; q.splits = 1; return sp == 1 && tile < 28 && dtp_gemm_fp8_supported(q) && !((p.flags & GF_GEGLU) && bn != 128); }
+  if (p.W8) return false;
   if (tile >= 20) { GemmParams q = p; q.splits = 1; return sp == 1 && dtp_gemm_wide_supported(q, tile - 20); }
   if ((p.flags & GF_GEGLU) && (bn != 128 || sp != 1)) return false;
   if (sp > 1 && ((p.flags & (GF_LNFOLD | GF_SOFTMAX16)) || p.batch > 1)) return false;
@@ -430,7 +442,8 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   // "k4|": bump when tile ids or pipelines change, so that a persisted table written by an older build is ignored
   int kl = snprintf(key, sizeof(key), "k4|%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
                     p.stride, p.lda, p.ldc, p.ldw, p.st_parts, p.Cin2, p.lda2);
-  if (p.batch > 1) snprintf(key + kl, sizeof(key) - kl, ",b%d", p.batch);
+  if (p.batch > 1) kl += snprintf(key + kl, sizeof(key) - kl, ",b%d", p.batch);
+  if (p.W8) snprintf(key + kl, sizeof(key) - kl, ",f8");
   auto it = c->tuned.find(key);
   if (it != c->tuned.end() && !tune_entry_valid(p, it->second.first, it->second.second)) {
     fprintf(stderr, "[dtp] tune table entry '%s' -> (%d, %d) does not fit the problem; re-tuning\n", key, it->second.first, it->second.second);
@@ -481,9 +494,17 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     };
     struct Cand { float ms; int tile, sp; };
     std::vector<Cand> cands;
-    for (int tile = 0; tile < 22; ++tile) {  // 4 tile shapes x 3 pipeline depths, the 256-row / 256-column tiles, the 8-wave wide tiles
+    for (int tile = 0; tile < 28; ++tile) {  // 4 tile shapes x 3 pipeline depths, the 256-row / 256-column tiles, the 8-wave wide tiles, fp8
       int bm = 0, bn = 0, ns = 0;
       if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) continue;
+      if ((p.W8 != nullptr) != (tile >= 24)) continue;  // an fp8 problem runs on the fp8 tiles only, and vice versa
+      if (tile >= 24) {
+        if (geglu && bn != 128) continue;
+        float ms;
+        RC(time_cfg(tile, 1, 5, &ms));
+        if (ms >= 0.f) cands.push_back({ms, tile, 1});
+        continue;
+      }
       if (tile >= 20) {  // gemm_wide_kernel: unsplit big-M problems only (at least half a wave of 256 CUs worth of tiles)
         GemmParams q = p;
         q.splits = 1;
@@ -575,6 +596,10 @@ static Op make_gemm_op(Ctx* c, GemmParams p, int tile, int bias_step_off) {
 int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg, RowStats* emit) {
   int tile = 0;
   dtp_gemm_pick(p, &tile, c->num_cu);
+  if (p.W8) {  // fp8: unsplit, one of the four fp8 tiles
+    p.splits = 1; p.kb_per_split = p.nkb;
+    tile = 24 + ((p.flags & GF_GEGLU) ? (p.M >= 512 ? 0 : 3) : (p.M >= 512 ? 0 : 2));
+  }
   if (c->autotune) RC(tune_gemm(c, p, &tile));
   if (emit) {  // the consumer must know how many partials this launch configuration writes per row
     int bm = 0, bn = 128, ns = 0;
@@ -592,9 +617,9 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   const double bytes = 2.0 * nb * (a_elems + (double)p.N * k_alg + (double)p.M * n_out);
   char lab[160];
   snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
-           p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? " geglu" : "", p.stride == 2 ? " s2" : "",
+           p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? (p.W8 ? " geglu fp8" : " geglu") : (p.W8 ? " fp8" : ""), p.stride == 2 ? " s2" : "",
            p.batch > 1 ? (" x" + std::to_string(p.batch)).c_str() : "");
-  const int kind = tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
+  const int kind = tile >= 24 ? PK_FP8 : tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
   const double flops = 2.0 * nb * p.M * (double)p.N * k_alg;
   prog_push(c, prog, kind, flops, bytes, make_gemm_op(c, p, tile, bias_step_off), lab);
   if (p.splits > 1) {  // a GroupNorm pushed next may take over the reduce (Builder::gn)
@@ -666,6 +691,11 @@ int Builder::linear(const T& x, const ConvW& w, const T* resid, int flags, T& y,
   }
   if (resid) { p.flags |= GF_RESID; p.R = resid->p; p.ldr = resid->ld; }
   if (emit && emit->buf) { p.flags |= GF_ROWSTATS; p.st_out = emit->buf; }
+  if (fp8 && w.w8) {
+    GemmParams q = p;
+    q.W8 = w.w8; q.ldw8 = w.ldw8; q.w_scale = w.w8_scale; q.a_scale = 1.0f; q.splits = 1;
+    if (dtp_gemm_fp8_supported(q)) p = q;  // otherwise the fp16 kernel takes it
+  }
   return push_gemm(c, prog, p, -1, (double)w.K, (emit && emit->buf) ? emit : nullptr);
 }
 

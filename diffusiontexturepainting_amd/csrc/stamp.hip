@@ -17,6 +17,7 @@ int load_imgenc_weights(Ctx* c);
 void dtp_gemm_init();
 void dtp_conv_halo_init();
 void dtp_gemm_wide_init();
+void dtp_gemm_fp8_init();
 
 #define VAE_SCALE 0.18215f
 
@@ -308,6 +309,7 @@ int dtp_finalize_weights(dtp_ctx* ctx) {
   dtp_gemm_init();
   dtp_conv_halo_init();
   dtp_gemm_wide_init();
+  dtp_gemm_fp8_init();
   RC(load_unet_weights(c));
   RC(load_vae_weights(c));
   bool has_clip = false;
@@ -558,6 +560,14 @@ int dtp_set_option(dtp_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "use_graph")) { c->use_graph = value != 0; return DTP_OK; }
   if (!strcmp(name, "autotune")) { c->autotune = value != 0; return DTP_OK; }
   if (!strcmp(name, "check_finite")) { c->check_finite = value != 0; return DTP_OK; }
+  if (!strcmp(name, "fp8_linear")) {
+    if (!c->unet_progs.empty() && c->fp8_linear != (value != 0)) {
+      dtp_set_error("dtp_set_option: fp8_linear must be chosen before the first UNet program is built");
+      return DTP_ERR_STATE;
+    }
+    c->fp8_linear = value != 0;
+    return DTP_OK;
+  }
   if (!strcmp(name, "fp8_attention")) {
     if (!c->unet_progs.empty() && c->fp8_attention != (value != 0)) {
       dtp_set_error("dtp_set_option: fp8_attention must be chosen before the first UNet program is built");

@@ -231,6 +231,11 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
     g.C = out.p; g.ldc = out.ld;
     g.bias = wm.b; g.R = x.p; g.ldr = x.ld;
     g.flags = GF_BIAS | GF_RESID;
+    if (b.fp8 && wm.w8) {
+      GemmParams q = g;
+      q.W8 = wm.w8; q.ldw8 = wm.ldw8; q.w_scale = wm.w8_scale; q.a_scale = 1.0f; q.splits = 1;
+      if (dtp_gemm_fp8_supported(q)) g = q;
+    }
     RC(push_gemm(b.c, b.prog, g, -1, (double)wm.K, nullptr));
     b.release(f); b.release(y3);
   }
@@ -298,7 +303,17 @@ int build_unet_prog(Ctx* c, int N, UNetProg& up) {
     }
   }
   // ---- main program
+  if (c->fp8_linear) {  // e4m3 copies of the transformer Linears (once per context)
+    UNetW& uw = c->unet;
+    std::vector<XfW*> all;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) all.push_back(&uw.down_xf[i][j]);
+    all.push_back(&uw.mid_xf);
+    for (int i = 1; i < 4; ++i) for (int j = 0; j < 3; ++j) all.push_back(&uw.up_xf[i][j]);
+    for (XfW* x : all)
+      for (ConvW* w : {&x->proj_in, &x->qkv, &x->out1, &x->ff1, &x->ff2_proj}) RC(ensure_w8(c, *w));
+  }
   Builder b{c, &up.main};
+  b.fp8 = c->fp8_linear;
   T x0;
   x0.p = up.in16; x0.B = N; x0.H = h; x0.W = h; x0.C = 16; x0.ld = 16;
   // Zero-copy skip connections: every up-path ResBlock consumes cat([x, skip], C).  The 12 concat buffers are

@@ -20,7 +20,7 @@ DEFAULT_SETTINGS = dict(steps=20, context_pad=150, tg_steps=20, cfg_weight=2.0, 
 
 
 class MI355ConditionalInpainter(ConditionalInpainterBase):
-    def __init__(self, resolution, device=0, weights="synthetic", max_batch=1, seed=42, use_graph=True, fp8_attention=None):
+    def __init__(self, resolution, device=0, weights="synthetic", max_batch=1, seed=42, use_graph=True, fp8_attention=None, fp8_linear=None):
         """weights: "synthetic" (seeded random tensors with the real shapes -- no checkpoints can be
         downloaded in this environment) or a dict {unet, vae, [lora], [clip], [penc]} of
         {diffusers key: tensor} state dicts (see weights.load_checkpoint_file)."""
@@ -56,6 +56,11 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
         self.fp8_attention = bool(fp8_attention)
         if self.fp8_attention:  # BASELINE configs[4]: UNet self-attention on the fp8 MX MFMA (before any program is built)
             check(self._lib.dtp_set_option(self._h, b"fp8_attention", 1), "dtp_set_option(fp8_attention)")
+        if fp8_linear is None:
+            fp8_linear = os.environ.get("DTP_FP8", "0") not in ("", "0")
+        self.fp8_linear = bool(fp8_linear)
+        if self.fp8_linear:  # ... and its transformer Linears / 1x1 convs
+            check(self._lib.dtp_set_option(self._h, b"fp8_linear", 1), "dtp_set_option(fp8_linear)")
         # noise: seeded once, never reseeded (trt_model.py:54, stable_diffusion_pipeline.py:154-156)
         self.generator = torch.Generator(device=self._device).manual_seed(seed)
         self.stream = torch.cuda.Stream(device=self._device)

@@ -59,8 +59,17 @@ def rowsum(wp, k):
     return out
 
 
+def quantize_w8(wp, k):
+    """packed f16 weights [rows, ldw] -> (e4m3 bytes [rows, roundup(k,128)], per-tensor scale) for the fp8 GEMM tiles 24..27."""
+    lib = _lib.load()
+    out = torch.zeros(wp.shape[0], _up(k, 128), dtype=torch.uint8, device=wp.device)
+    sc = C.c_float()
+    check(lib.dtp_op_quantize_w8(ptr(wp), wp.stride(0), k, wp.shape[0], ptr(out), out.shape[1], C.byref(sc), _stream()), "quantize_w8")
+    return out, sc.value
+
+
 def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, out=None, lda=None, lns=None, ln_eps=1e-5, batch=0,
-         sm_valid=0, bias_shared=False, tail=None, row_stats=False, stats_in=None):
+         sm_valid=0, bias_shared=False, tail=None, row_stats=False, stats_in=None, w8=None, w_scale=1.0, a_scale=1.0, layernorm=False):
     """a f16 [M, >=K] row-major; wp packed weights; returns f16 [M, N] (or [M, N/2] with GEGLU).
     batch > 1: a is [batch*M, K] (problem b = rows b*M..), wp is [batch*Npad, Kpad], bias / lns are [batch*Npad]."""
     lib = _lib.load()
@@ -89,6 +98,11 @@ def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, ou
     if tail is not None:  # second activation matrix: supplies the last tail.shape[1] columns of the contraction
         d.A2, d.lda2, d.Cin2 = tail.data_ptr(), tail.stride(0), tail.shape[1]
         d.K = k + tail.shape[1]
+    if w8 is not None:  # fp8 tiles: the e4m3 weight copy + scales; layernorm=True applies (x - mean) * rstd while staging A
+        d.W8, d.ldw8, d.w_scale, d.a_scale = w8.data_ptr(), w8.stride(0), w_scale, a_scale
+        if layernorm:
+            d.flags |= GF_LNFOLD
+            d.ln_eps = ln_eps
     st = None
     if row_stats:  # also return the per-row (sum, sumsq) partials of the fp16 output: f32 [parts, M, 2]
         st = torch.zeros((n + 63) // 64, a.shape[0], 2, dtype=torch.float32, device=a.device)

@@ -124,7 +124,7 @@ int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes);
  * 128x128 / 128x64 / 64x64 / 64x128), 12 = attention_kernel, 13 = GroupNorm (stats+apply or fused),
  * 14 = layernorm, 15 = concat/elementwise, 16 = softmax_rows, 17-20 = conv_halo_kernel<8,16,64> / <8,16,128> / <8,8,64> /
  * <8,8,128> (halo-tiled 3x3 conv), 21-24 = gemm_kernel<256,128,2> / <256,128,3> / <128,256,2> / <128,256,3>,
- * 25-26 = gemm_wide_kernel<256,256> / <256,320> (8-wave wide tiles).  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
+ * 25-26 = gemm_wide_kernel<256,256> / <256,320> (8-wave wide tiles), 27 = gemm_fp8_kernel (all four tiles).  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
  * dtp_profile(ctx, 0) switches back to graph replay.  The nvtx/cudaEvent hooks of
  * stable_diffusion_pipeline.py:146-149,486-503 are the reference counterpart. */
 typedef struct { int kind; int launches; double ms; double flops; double bytes; } dtp_prof_row;
@@ -135,8 +135,9 @@ int dtp_profile_dump(dtp_ctx* ctx, const char* path);
 /* options: "use_graph" (default 1): replay captured hipGraphs; "autotune" (default 1): time tile x split-K candidates per
  * contraction shape when a launch program is built; "check_finite" (default 0): after every stamp ONE reduction over the
  * final latents and the decoded image looks for NaN/inf (the reference asserts `not isnan` after every step with a host
- * sync each, stable_diffusion_pipeline.py:415) -- read the verdict with dtp_last_stamp_finite; "fp8_attention" (default 0): the
- * UNet's self-attention runs on the fp8 MX MFMA (BASELINE configs[4]; choose before the first stamp). */
+ * sync each, stable_diffusion_pipeline.py:415) -- read the verdict with dtp_last_stamp_finite; "fp8_attention" / "fp8_linear"
+ * (default 0): the UNet's self-attention / its transformer Linears and 1x1 convs (proj_in, q/k/v, to_out, GEGLU FFN,
+ * ff.net.2 + proj_out) run on the fp8 (e4m3) MX MFMA -- BASELINE configs[4]; choose before the first stamp. */
 int dtp_set_option(dtp_ctx* ctx, const char* name, int value);
 /* *finite = 1 if the last stamp (run with "check_finite" on) produced only finite values, 0 otherwise.  Blocks until that
  * stamp has finished; DTP_ERR_STATE if the option was off. */
@@ -159,7 +160,8 @@ typedef struct {
   int tile;          /* -1 = heuristic; gemm_kernel: shape + 4*(stages-2), shape 0:128x128 1:128x64 2:64x64 3:64x128 (MxN),
                         stages 2..4; 12..15 = conv_halo_kernel (8x16|8x8 pixel tile) x (64|128 channels), needs Wcb;
                         16..19 = gemm_kernel 256x128 (2|3 stages), 128x256 (2|3 stages);
-                        20 / 21 = gemm_wide_kernel 256x256 / 256x320 (8 waves; unsplit, N % 8 == 0; 21: no GEGLU) */
+                        20 / 21 = gemm_wide_kernel 256x256 / 256x320 (8 waves; unsplit, N % 8 == 0; 21: no GEGLU);
+                        24..27 = gemm_fp8_kernel 128x128 / 128x64 / 64x64 / 64x128 (needs W8; dense, unsplit) */
   int splits;        /* 0 = heuristic; >=1 = forced split-K factor */
   const float* lns;  /* DTP_GF_LNFOLD: row sums of the packed weights (dtp_op_rowsum) */
   float ln_eps;
@@ -176,6 +178,10 @@ typedef struct {
   const float* st_in;/* DTP_GF_LNFOLD: row statistics of A handed over by its producer ([st_parts][M][2]); NULL = computed in-kernel */
   int st_parts;
   int st_parts_out;  /* written by dtp_op_gemm: number of partials per row the chosen tile emitted into st_out */
+  const void* W8;    /* tile 24..27 (gemm_fp8_kernel, BASELINE configs[4]): e4m3 copy of the packed weights from dtp_op_quantize_w8,
+                        [rows][ldw8] bytes, K padded to 128; with DTP_GF_LNFOLD the LayerNorm is applied while A is staged */
+  int ldw8;
+  float a_scale, w_scale; /* A8 = e4m3(A / a_scale), W8 = e4m3(W / w_scale) (powers of two); the product is applied to the accumulators */
 } dtp_gemm_desc;
 enum { DTP_GF_BIAS = 1, DTP_GF_BIAS_M = 2, DTP_GF_RESID = 4, DTP_GF_GEGLU = 8, DTP_GF_GELU = 64, DTP_GF_QUICKGELU = 128,
        DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512, DTP_GF_LNFOLD = 1024, DTP_GF_ROWSTATS = 2048, DTP_GF_SOFTMAX16 = 4096 };
@@ -186,6 +192,9 @@ int dtp_op_pack_linear(const float* w, void* out, int N, int K, int ldw, int geg
 /* w f32 [Cout][Cin][3][3] (or 1x1) -> out f16 [rows][ldw], k = tap*Cin_pad + ci (caller zero-fills out) */
 /* out[r] = sum_k w[r][k] over packed fp16 rows (the `lns` vector of a LayerNorm-folded GEMM) */
 int dtp_op_rowsum(const void* w, int ld, int K, float* out, int rows, dtp_stream s);
+/* packed f16 weights [rows][ldw] -> e4m3 [rows][ldw8] (ldw8 = K rounded up to 128) with one per-tensor power-of-two scale
+ * (amax / scale <= 448), returned in *w_scale.  Synchronises the stream once (it reads the amax back). */
+int dtp_op_quantize_w8(const void* w, int ldw, int K, int rows, void* out, int ldw8, float* w_scale, dtp_stream s);
 int dtp_op_pack_conv(const float* w, void* out, int Cout, int Cin, int Cin_pad, int taps, int ldw, dtp_stream s);
 /* w f32 [Cout][Cin][3][3] -> out f16 [rows][ldw], k' = ((ci/64)*9 + tap)*64 + ci%64 (Cin % 64 == 0; caller zero-fills out) */
 int dtp_op_pack_conv_cb(const float* w, void* out, int Cout, int Cin, int ldw, dtp_stream s);

@@ -126,25 +126,28 @@ def test_256_20steps_matches_cpu_oracle(weights):
     assert err <= 1e-2 and m.stamp_info()["unet_evals"] == 19
 
 
-FP8_PIXEL_TOL = 3e-2  # BASELINE configs[4]: fp8 (e4m3) attention operands cost more than the 1e-2 of the fp16 path
+FP8_ATTN_PIXEL_TOL = 3e-2  # BASELINE configs[4], attention only: fp8 (e4m3) operands cost more than the 1e-2 of the fp16 path
+FP8_FULL_PIXEL_TOL = 6e-2  # ... with the transformer Linears / 1x1 convs in fp8 as well.  Seeded RANDOM weights are the worst case for
+# a 3-mantissa-bit contraction: the terms of every dot product are incoherent, so each GEMM output carries ~5 % relative noise
+# (with trained weights the sums are coherent and the relative error is a fraction of that); measured 3.9e-2.
 
 
-def test_config4_256_8steps_fp8_attention(weights):
-    """configs[4]: 256 x 256, 8 DDIM steps with the UNet's self-attention on the fp8 MX MFMA, against the fp32 CPU oracle.
-    Stated tolerance: max-abs pixel error <= 3e-2 (the fp16 path of the same stamp is gated at 1e-2 and measures ~2e-3)."""
+def test_config4_256_8steps_fp8(weights):
+    """configs[4]: 256 x 256, 8 DDIM steps against the fp32 CPU oracle in three precisions: fp16 (gate 1e-2), fp8 self-attention
+    (stated tolerance 3e-2), fp8 self-attention + transformer Linears / 1x1 convs (stated tolerance 6e-2, see above)."""
     from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
     from oracle import pipeline
     canvas, brush, cond, uncond, lat, eps = _inputs(1, 256, 400)
     st = dict(steps=8, context_pad=150, tg_steps=8, cfg_weight=2.0, tg_weight=1.0)
     ref = pipeline.generate_raw(weights[1], brush, cond, uncond, canvas, lat, eps, **st)
     errs = {}
-    for fp8 in (True, False):
-        m = MI355ConditionalInpainter(256, device=0, weights=weights[0], max_batch=1, fp8_attention=fp8)
+    for fp8 in ("full", "attention", False):
+        m = MI355ConditionalInpainter(256, device=0, weights=weights[0], max_batch=1, fp8_attention=bool(fp8), fp8_linear=(fp8 == "full"))
         m.set_conditioning(cond, uncond, brush)
         got = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
         torch.cuda.synchronize()
         errs[fp8] = (got.cpu() - ref).abs().max().item()
-        print(f"256^2 / 8 steps, fp8_attention={fp8}: max abs pixel error {errs[fp8]:.2e}, stage ms {m.stage_times_ms()}")
+        print(f"256^2 / 8 steps, fp8 attention + linear={fp8}: max abs pixel error {errs[fp8]:.2e}, stage ms {m.stage_times_ms()}")
         assert torch.isfinite(got).all() and m.stamp_info()["unet_evals"] == 7
-    assert errs[False] <= 1e-2 and errs[True] <= FP8_PIXEL_TOL
-    assert errs[True] != errs[False]  # the option really switched the kernels
+    assert errs[False] <= 1e-2 and errs["attention"] <= FP8_ATTN_PIXEL_TOL and errs["full"] <= FP8_FULL_PIXEL_TOL
+    assert len({errs[False], errs["attention"], errs["full"]}) == 3  # the options really switched the kernels

@@ -446,3 +446,70 @@ def test_attention_fp8_peaked_rows_and_views(ops):
     from diffusiontexturepainting_amd._lib import DtpError
     with pytest.raises(DtpError):  # d = 64 has no spare contraction column for the shift: loud, not silent
         ops.attention_fp8(rnd(1, 64, 512, seed=1).cuda(), rnd(1, 64, 512, seed=2).cuda(), rnd(1, 64, 512, seed=3).cuda(), 8)
+
+
+def _e4(t, scale=1.0):
+    """what the kernels feed the fp8 MFMA: e4m3(t / scale), dequantised back to fp32"""
+    return (t.float() / scale).to(torch.float8_e4m3fn).float() * scale
+
+
+@pytest.mark.parametrize("m,n,k,tile", [(300, 320, 320, 24), (700, 640, 1280, 24), (130, 1280, 320, 26), (64, 768, 768, 27), (513, 320, 1280, 25),
+                                        (200, 320, 400, 26)])
+def test_gemm_fp8(ops, m, n, k, tile):
+    """fp8 (e4m3) GEMM on the MX MFMA (configs[4]): the products of e4m3 operands are exact in the fp32 accumulator, so against the
+    same contraction on the e4m3-rounded operands only the summation order differs (2e-3); against exact fp32 it is the
+    operand rounding (3 mantissa bits each: a few percent of the output range)."""
+    a, w = rnd(m, k, seed=201), rnd(n, k, seed=202, scale=k ** -0.5)
+    bias = torch.randn(n, generator=torch.Generator().manual_seed(203))
+    r = rnd(m, n, seed=204)
+    wp = ops.pack_linear(w.float().cuda())
+    w8, ws = ops.quantize_w8(wp, k)
+    assert ws > 0 and abs(math.log2(ws) - round(math.log2(ws))) < 1e-6  # a power of two
+    assert (w.float().abs().max() / ws) <= 448 and (w.float().abs().max() / ws) > 112  # the tensor uses the top of the range
+    got = ops.gemm(a.cuda(), wp, n, k, bias=bias.cuda(), resid=r.cuda(), tile=tile, w8=w8, w_scale=ws)
+    ref8 = F.linear(_e4(a), _e4(w, ws), bias) + r.float()
+    close(got, ref8, tol=2e-3)
+    ref = F.linear(a.float(), w.float(), bias) + r.float()
+    assert (got.float().cpu() - ref).abs().max().item() <= 6e-2 * ref.abs().max().item()
+
+
+def test_gemm_fp8_layernorm_geglu_and_two_operands(ops):
+    from diffusiontexturepainting_amd._lib import GF_BIAS, GF_GEGLU
+    # (1) LayerNorm applied while A is staged (consumer of a residual stream with a large mean), GEGLU epilogue
+    m, c = 300, 320
+    x = rnd(m, c, seed=210) * 1.5 + 6.0
+    w = rnd(8 * c, c, seed=211, scale=c ** -0.5).float()
+    g = torch.Generator().manual_seed(212)
+    gamma, beta, bias = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(8 * c, generator=g)
+    wg = w * gamma[None]
+    b2 = bias + w @ beta
+    f = torch.arange(4 * c)
+    perm = torch.empty(8 * c, dtype=torch.long)
+    perm[f] = (f // 64) * 128 + f % 64
+    perm[4 * c + f] = (f // 64) * 128 + 64 + f % 64
+    bp = torch.empty_like(b2)
+    bp[perm] = b2
+    wp = ops.pack_linear(wg.cuda(), geglu=True)
+    w8, ws = ops.quantize_w8(wp, c)
+    got = ops.gemm(x.cuda(), wp, 8 * c, c, bias=bp.cuda(), flags=GF_GEGLU | GF_BIAS, tile=24, w8=w8, w_scale=ws, layernorm=True)
+    xn = F.layer_norm(x.float(), (c,), None, None, 1e-5)
+    h8 = F.linear(_e4(xn), _e4(wg, ws), b2)
+    a8, g8 = h8.chunk(2, dim=-1)
+    # the kernel's fp32 (x - mean) * rstd and torch's layer_norm differ in the last bits, and a value that sits on an e4m3
+    # rounding boundary then lands on the neighbouring code (6 % of that element): not bit-comparable like the plain case
+    close(got, a8 * F.gelu(g8), tol=2.5e-2)
+    h = F.linear(F.layer_norm(x.float(), (c,), gamma, beta, 1e-5), w, bias)
+    ref = h[:, : 4 * c] * F.gelu(h[:, 4 * c:])
+    assert (got.float().cpu() - ref).abs().max().item() <= 8e-2 * ref.abs().max().item()
+    # (2) [f | r] . [W1 | W2]^T with f and r in separate buffers (ff.net.2 + proj_out), + row statistics of the output
+    m, k1, k2, n = 260, 1280, 320, 320
+    fa, rb = rnd(m, k1, seed=213), rnd(m, k2, seed=214)
+    w = rnd(n, k1 + k2, seed=215, scale=(k1 + k2) ** -0.5)
+    res = rnd(m, n, seed=216)
+    wp = ops.pack_linear(w.float().cuda())
+    w8, ws = ops.quantize_w8(wp, k1 + k2)
+    got, st = ops.gemm(fa.cuda(), wp, n, k1, resid=res.cuda(), tail=rb.cuda(), tile=26, w8=w8, w_scale=ws, row_stats=True)
+    ref8 = F.linear(torch.cat([_e4(fa), _e4(rb)], dim=1), _e4(w, ws)) + res.float()
+    close(got, ref8, tol=2e-3)
+    tot = st.sum(dim=0).cpu()
+    assert torch.allclose(tot[:, 0], got.float().cpu().sum(dim=1), rtol=1e-4, atol=1e-2)
