@@ -411,7 +411,7 @@ static bool tune_entry_valid(const GemmParams& p, int tile, int sp) {
   if (halo) return p.Wcb && dtp_conv_halo_supported(p) && p.batch <= 1;
   int bm = 0, bn = 0, ns = 0;
   if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) return false;
-  if (tile >= 24) { GemmParams q = p; q.splits = 1; return sp == 1 && tile < 28 && dtp_gemm_fp8_supported(q) && !((p.flags & GF_GEGLU) && bn != 128); }
+  if (tile >= 24) { GemmParams q = p; q.splits = 1; return sp == 1 && tile <= 28 && dtp_gemm_fp8_supported(q) && !((p.flags & GF_GEGLU) && (bn % 128)); }
   if (p.W8) return false;
   if (tile >= 20) { GemmParams q = p; q.splits = 1; return sp == 1 && dtp_gemm_wide_supported(q, tile - 20); }
   if ((p.flags & GF_GEGLU) && (bn != 128 || sp != 1)) return false;
@@ -494,12 +494,13 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     };
     struct Cand { float ms; int tile, sp; };
     std::vector<Cand> cands;
-    for (int tile = 0; tile < 28; ++tile) {  // 4 tile shapes x 3 pipeline depths, the 256-row / 256-column tiles, the 8-wave wide tiles, fp8
+    for (int tile = 0; tile < 29; ++tile) {  // 4 tile shapes x 3 pipeline depths, the 256-row / 256-column tiles, the 8-wave wide tiles, fp8
       int bm = 0, bn = 0, ns = 0;
       if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) continue;
       if ((p.W8 != nullptr) != (tile >= 24)) continue;  // an fp8 problem runs on the fp8 tiles only, and vice versa
       if (tile >= 24) {
-        if (geglu && bn != 128) continue;
+        if (geglu && (bn % 128)) continue;
+        if (tile == 28 && (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) < 96) continue;
         float ms;
         RC(time_cfg(tile, 1, 5, &ms));
         if (ms >= 0.f) cands.push_back({ms, tile, 1});

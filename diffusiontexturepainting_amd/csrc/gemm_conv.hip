@@ -575,6 +575,7 @@ bool dtp_gemm_tile_dims(int tile, int* bm, int* bn, int* ns) {
   if (tile >= 16 && tile < 20) { *bm = tile < 18 ? 256 : 128; *bn = tile < 18 ? 128 : 256; *ns = 2 + (tile & 1); return true; }
   if (tile == 20 || tile == 21) { *bm = 256; *bn = tile == 20 ? 256 : 320; *ns = 2; return true; }  // gemm_wide_kernel (8 waves)
   if (tile >= 24 && tile < 28) { *bm = sm[tile & 3]; *bn = sn[tile & 3]; *ns = 2; return true; }     // gemm_fp8_kernel
+  if (tile == 28) { *bm = 256; *bn = 256; *ns = 2; return true; }                                    // gemm_fp8_kernel, 8 waves
   return false;
 }
 
@@ -611,7 +612,7 @@ void dtp_gemm_pick(GemmParams& p, int* tile, int num_cu) {
 int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
   if (p.nkb <= 0 || p.M <= 0 || p.N <= 0) { dtp_set_error("gemm: empty problem"); return DTP_ERR_ARG; }
   if (tile == 20 || tile == 21) return dtp_launch_gemm_wide(p, tile - 20, s);
-  if (tile >= 24 && tile < 28) return dtp_launch_gemm_fp8(p, tile - 24, s);
+  if (tile >= 24 && tile <= 28) return dtp_launch_gemm_fp8(p, tile - 24, s);
   if ((p.lda & 7) || (p.ldw & 7)) { dtp_set_error("gemm: lda/ldw must be multiples of 8"); return DTP_ERR_ARG; }
   if ((p.flags & GF_CONV3) && (p.Cin & 7)) { dtp_set_error("conv: Cin must be a multiple of 8"); return DTP_ERR_ARG; }
   if (p.A2 && (p.flags & GF_CONV3) && (((9 * p.Cin) & 63) || (p.Cin2 & 63) || (p.lda2 & 7) || p.stride != 1)) {

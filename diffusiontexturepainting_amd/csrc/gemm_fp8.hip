@@ -47,12 +47,34 @@ __device__ __forceinline__ unsigned cvt4f(float a, float b, float c, float d, fl
   return __builtin_bit_cast(unsigned, r);
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_fp8_kernel(const GemmParams p) {
-  constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int AR = BM / 32, WR = BN / 32;
+// WM x WN waves; 2 x 2 for the four small tiles (one wave per SIMD), 2 x 4 = 8 waves for the 256 x 256 tile of the big-M problems
+// (two waves per SIMD: one wave's conversions / LDS traffic under the other's MFMAs; at the same LDS bytes per k-block a
+// k-block is twice as deep as in fp16)
+// two hand-issued ds_read_b128 halves -> one 32-byte MFMA operand
+static __device__ __forceinline__ v8i frag8(f16x8 lo, f16x8 hi) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 a = __builtin_bit_cast(i32x4, lo), b = __builtin_bit_cast(i32x4, hi);
+  return v8i{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+// s_waitcnt lgkmcnt(N) that every fragment of the step depends on (12 reads: 2 weight + 4 activation fragments of two halves)
+template <int N>
+static __device__ __forceinline__ void wait_lds_all(f16x8 (&f)[12]) {
+  asm volatile("s_waitcnt lgkmcnt(%12)"
+               : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11])
+               : "n"(N));
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_fp8_kernel(const GemmParams p) {
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int RPR = NW * 8;                  // LDS rows filled per staging round
+  constexpr int AR = BM / RPR, WR = BN / RPR;
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int SLD = BN + 8;
+  constexpr int EP = (BM * SLD * 2 <= 2 * STAGE) ? 1 : 2, ROWS_EP = BM / EP;  // epilogue passes through the LDS staging tile
+  static_assert(BM % RPR == 0 && BN % RPR == 0 && ROWS_EP % WTM == 0 && ROWS_EP * SLD * 2 <= 2 * STAGE, "tile / wave grid mismatch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -74,18 +96,17 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const GemmParams p) {
   const int lrow = wave * 8 + (lane >> 3);
   const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);  // 16-element chunk of the k-block this thread brings in
   const int dense_k1 = p.K - p.Cin2;                 // two-operand GEMM: first column read from A2 (a multiple of 128)
-  const f16 *a_row[AR], *a2_row[AR];
+  int a_m[AR];  // row index of every piece (-1 past M); pointers are formed at load time (registers: the 8-wave tile is at its budget)
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    const int m = m0 + i * 32 + lrow;
-    a_row[i] = (m < p.M) ? p.A + (size_t)m * p.lda : nullptr;
-    a2_row[i] = (m < p.M && p.A2) ? p.A2 + (size_t)m * p.lda2 : nullptr;
+    const int m = m0 + i * RPR + lrow;
+    a_m[i] = (m < p.M) ? m : -1;
   }
   const int n_rows_packed = (p.N + 127) & ~127;
   const unsigned char* w_row[WR];
 #pragma unroll
   for (int i = 0; i < WR; ++i) {
-    const int n = n0 + i * 32 + lrow;
+    const int n = n0 + i * RPR + lrow;
     w_row[i] = (n < n_rows_packed) ? p.W8 + (size_t)n * p.ldw8 + chunk * 16 : nullptr;
   }
 
@@ -94,7 +115,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const GemmParams p) {
   const bool ln = (p.flags & GF_LNFOLD) != 0;
   const int st_rows = p.st_rows > 0 ? p.st_rows : p.M;
   if (ln && p.st_in) {
-    for (int r = tid; r < BM; r += 256) {
+    for (int r = tid; r < BM; r += NT) {
       const int m = m0 + r;
       float s1 = 0.f, s2 = 0.f;
       if (m < p.M)
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const GemmParams p) {
     }
   } else if (ln) {
     const int l16 = tid & 15, nch = p.K >> 3;
-    for (int r0 = 0; r0 < BM; r0 += 16) {
+    for (int r0 = 0; r0 < BM; r0 += NT / 16) {
       const int r = r0 + (tid >> 4), m = m0 + r;
       float s1 = 0.f, s2 = 0.f;
       if (m < p.M) {
@@ -132,20 +153,22 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const GemmParams p) {
   float mean_r[AR], rstd_r[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    mean_r[i] = ln ? rowst[2 * (i * 32 + lrow)] : 0.f;
-    rstd_r[i] = ln ? rowst[2 * (i * 32 + lrow) + 1] : 1.f;
+    mean_r[i] = ln ? rowst[2 * (i * RPR + lrow)] : 0.f;
+    rstd_r[i] = ln ? rowst[2 * (i * RPR + lrow) + 1] : 1.f;
   }
 
   f16x8 areg[AR][2];
-  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   auto load_a = [&](int t) {  // k-block t: this thread's 16 halfs of every row piece (zeros past K / past M)
     const int k0 = t * 128 + chunk * 16;
+    const bool tail = p.A2 && k0 >= dense_k1;
+    const f16* base = tail ? p.A2 + (k0 - dense_k1) : p.A + k0;
+    const int ld = tail ? p.lda2 : p.lda;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      const f16* src = nullptr;
-      if (k0 < p.K) src = (p.A2 && k0 >= dense_k1) ? (a2_row[i] ? a2_row[i] + (k0 - dense_k1) : nullptr) : (a_row[i] ? a_row[i] + k0 : nullptr);
-      areg[i][0] = src ? *(const f16x8*)src : zero8;
-      areg[i][1] = src ? *(const f16x8*)(src + 8) : zero8;
+      // unconditional loads (a conditional load costs an exec-mask branch and spills): out-of-range pieces read the zero page
+      const f16* src = (k0 < p.K && a_m[i] >= 0) ? base + (size_t)a_m[i] * ld : p.zero;
+      areg[i][0] = *(const f16x8*)src;
+      areg[i][1] = *(const f16x8*)(src + 8);
     }
   };
   auto store_a = [&](int stage, int t) {  // (LayerNorm) -> e4m3 -> the LDS slot the DMA would have written
@@ -167,13 +190,13 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const GemmParams p) {
         w[2] = cvt4(hi[0], hi[1], hi[2], hi[3], p.a_scale);
         w[3] = cvt4(hi[4], hi[5], hi[6], hi[7], p.a_scale);
       }
-      *(u32x4*)(As + (i * 32 + lrow) * 128 + (lane & 7) * 16) = w;
+      *(u32x4*)(As + (i * RPR + lrow) * 128 + (lane & 7) * 16) = w;
     }
   };
   auto issue_w = [&](int stage, int t) {
     char* Ws = smem + stage * STAGE + BM * 128;
 #pragma unroll
-    for (int i = 0; i < WR; ++i) glds16(w_row[i] ? (const void*)(w_row[i] + (size_t)t * 128) : (const void*)p.zero, Ws + (i * 32 + wave * 8) * 128);
+    for (int i = 0; i < WR; ++i) glds16(w_row[i] ? (const void*)(w_row[i] + (size_t)t * 128) : (const void*)p.zero, Ws + (i * RPR + wave * 8) * 128);
   };
 
   f32x16 acc[TN][TM];
@@ -183,7 +206,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const GemmParams p) {
     for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int wn0 = (wave & 1) * (BN / 2), wm0 = (wave >> 1) * (BM / 2);
+  const int wn0 = (wave % WN) * WTN, wm0 = (wave / WN) * WTM;
   const int frow = lane & 31, fhalf = lane >> 5;
 
   issue_w(0, 0);
@@ -197,16 +220,51 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const GemmParams p) {
     if (more) { issue_w(cur ^ 1, t + 1); load_a(t + 1); }
     const char* As = smem + cur * STAGE;
     const char* Ws = As + BM * 128;
+    if constexpr (NW > 4) {
+      // 8-wave tile: 128 accumulator registers leave room for ONE K = 64 step of fragments next to the staged activations, so
+      // the fragment reads are issued by hand (the compiler would hoist both steps' reads above the MFMAs and spill)
+      const uint32_t a_lds = lds_addr(As), w_lds = lds_addr(Ws);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c0 = 4 * j + 2 * fhalf;
+        __builtin_amdgcn_sched_barrier(0);  // the MFMAs of step 0 stay above the reads of step 1
+        f16x8 fr[2 * (TN + TM)];
+#pragma unroll
+        for (int q = 0; q < TN; ++q) {
+          const int row = wn0 + q * 32 + frow, key = (row >> 1) & 7;
+          fr[2 * q] = lds_read16(w_lds + row * 128 + ((c0 ^ key) << 4));
+          fr[2 * q + 1] = lds_read16(w_lds + row * 128 + (((c0 + 1) ^ key) << 4));
+        }
+#pragma unroll
+        for (int q = 0; q < TM; ++q) {
+          const int row = wm0 + q * 32 + frow, key = (row >> 1) & 7;
+          fr[2 * (TN + q)] = lds_read16(a_lds + row * 128 + ((c0 ^ key) << 4));
+          fr[2 * (TN + q) + 1] = lds_read16(a_lds + row * 128 + (((c0 + 1) ^ key) << 4));
+        }
+#pragma unroll
+        for (int q = 0; q < TM; ++q) {  // activation fragment q is complete once 2 * (TM - 1 - q) reads are still in flight
+          static_assert(TM == 4, "the counted waits below are written for four activation fragments");
+          if (q == 0) wait_lds_all<6>(fr);
+          else if (q == 1) wait_lds_all<4>(fr);
+          else if (q == 2) wait_lds_all<2>(fr);
+          else wait_lds_all<0>(fr);
+          const v8i af = frag8(fr[2 * (TN + q)], fr[2 * (TN + q) + 1]);
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+            acc[i][q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag8(fr[2 * i], fr[2 * i + 1]), af, acc[i][q], 0, 0, 0, UNIT_SCALES, 0, UNIT_SCALES);
+        }
+        // pin the MFMAs of this step between the hand-issued reads (without it they are sunk below the next step's reads and
+        // into both arms of the staging branch, with every fragment of the k-block live at once)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int q = 0; q < TM; ++q) asm volatile("" : "+v"(acc[i][q]));
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {  // two K = 64 MFMAs per 32 x 32 block and k-block
-      v8i af[TM], wf[TN];
+      v8i wf[TN];
       const int c0 = 4 * j + 2 * fhalf;
-#pragma unroll
-      for (int q = 0; q < TM; ++q) {
-        const int row = wm0 + q * 32 + frow, key = (row >> 1) & 7;
-        const u32x4 x0 = *(const u32x4*)(As + row * 128 + ((c0 ^ key) << 4)), x1 = *(const u32x4*)(As + row * 128 + (((c0 + 1) ^ key) << 4));
-        af[q] = v8i{(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
-      }
 #pragma unroll
       for (int q = 0; q < TN; ++q) {
         const int row = wn0 + q * 32 + frow, key = (row >> 1) & 7;
@@ -214,10 +272,15 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const GemmParams p) {
         wf[q] = v8i{(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
       }
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+      for (int q = 0; q < TM; ++q) {  // one activation fragment at a time: it meets every weight fragment, then dies
+        const int row = wm0 + q * 32 + frow, key = (row >> 1) & 7;
+        const u32x4 x0 = *(const u32x4*)(As + row * 128 + ((c0 ^ key) << 4)), x1 = *(const u32x4*)(As + row * 128 + (((c0 + 1) ^ key) << 4));
+        const v8i af = {(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
 #pragma unroll
-        for (int q = 0; q < TM; ++q)
-          acc[i][q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[i], af[q], acc[i][q], 0, 0, 0, UNIT_SCALES, 0, UNIT_SCALES);
+        for (int i = 0; i < TN; ++i)
+          acc[i][q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[i], af, acc[i][q], 0, 0, 0, UNIT_SCALES, 0, UNIT_SCALES);
+      }
+    }
     }
     if (more) store_a(cur ^ 1, t + 1);  // the other stage was last read one iteration ago (barrier below)
     wait_vmcnt<0>();
@@ -225,83 +288,91 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const GemmParams p) {
     cur ^= 1;
   }
 
-  // ---------------------------------------------------------------- epilogue (layout and fusions as in gemm_kernel)
+  // ---------------------------------------------------------------- epilogue (layout and fusions as in gemm_kernel / gemm_wide_kernel)
   const float sc = p.a_scale * p.w_scale;
   f16* stg = (f16*)smem;
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int ml = wm0 + j * 32 + frow;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int nl = wn0 + i * 32 + 8 * q + 4 * fhalf;
-        f16x4 v = {(f16)(acc[i][j][4 * q] * sc), (f16)(acc[i][j][4 * q + 1] * sc), (f16)(acc[i][j][4 * q + 2] * sc), (f16)(acc[i][j][4 * q + 3] * sc)};
-        *(f16x4*)(stg + ml * SLD + nl) = v;
-      }
-    }
-  __syncthreads();
   const int fl = p.flags;
-  if (fl & GF_GEGLU) {
-    if constexpr (BN % 128 == 0) {
-      constexpr int G = BN / 128, IT = G * 8;
-      const int item = tid % IT, g = item >> 3, nc = item & 7;
-      const int ca = g * 128 + nc * 8, cg = ca + 64;
-      float ba[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (fl & GF_BIAS) {
+  constexpr int NC = BN / 8;
+  static_assert(NT % NC == 0, "a thread owns one column chunk");
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ba[e] = p.bias[n0 + ca + e]; bg[e] = p.bias[n0 + cg + e]; }
+  for (int e = 0; e < EP; ++e) {
+    if (e > 0) __syncthreads();  // the staging tile of the previous pass was consumed (pass 0: the k-loop ended on a barrier)
+    if (wm0 / ROWS_EP == e) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int ml = wm0 - e * ROWS_EP + j * 32 + frow;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nl = wn0 + i * 32 + 8 * q + 4 * fhalf;
+            f16x4 v = {(f16)(acc[i][j][4 * q] * sc), (f16)(acc[i][j][4 * q + 1] * sc), (f16)(acc[i][j][4 * q + 2] * sc), (f16)(acc[i][j][4 * q + 3] * sc)};
+            *(f16x4*)(stg + ml * SLD + nl) = v;
+          }
+        }
+    }
+    __syncthreads();
+    const int mbase = m0 + e * ROWS_EP;
+    if (fl & GF_GEGLU) {
+      if constexpr (BN % 128 == 0) {
+        constexpr int G = BN / 128, IT = G * 8;
+        const int item = tid % IT, g = item >> 3, nc = item & 7;
+        const int ca = g * 128 + nc * 8, cg = ca + 64;
+        float ba[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (fl & GF_BIAS) {
+#pragma unroll
+          for (int x = 0; x < 8; ++x) { ba[x] = p.bias[n0 + ca + x]; bg[x] = p.bias[n0 + cg + x]; }
+        }
+        const bool col_ok = (n0 + cg + 8 <= p.N);
+        for (int idx = tid; idx < ROWS_EP * IT; idx += NT) {
+          const int ml = idx / IT, m = mbase + ml;
+          if (m >= p.M || !col_ok) continue;
+          const f16x8 a = *(const f16x8*)(stg + ml * SLD + ca), gt = *(const f16x8*)(stg + ml * SLD + cg);
+          f16x8 o;
+#pragma unroll
+          for (int x = 0; x < 8; ++x) o[x] = (f16)(((float)a[x] + ba[x]) * gelu_erf((float)gt[x] + bg[x]));
+          *(f16x8*)((f16*)p.C + (size_t)m * p.ldc + (size_t)((n0 / 128 + g) * 64) + nc * 8) = o;
+        }
       }
-      const bool col_ok = (n0 + cg + 8 <= p.N);
-      for (int idx = tid; idx < BM * IT; idx += 256) {
-        const int ml = idx / IT, m = m0 + ml;
-        if (m >= p.M || !col_ok) continue;
-        const f16x8 a = *(const f16x8*)(stg + ml * SLD + ca), gt = *(const f16x8*)(stg + ml * SLD + cg);
+      continue;
+    }
+    const int nc = tid % NC, n = n0 + nc * 8;
+    const bool col_ok = (n + 8 <= p.N);
+    float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (col_ok && (fl & GF_BIAS)) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) bv[x] = p.bias[n + x];
+    }
+    for (int idx = tid; idx < ROWS_EP * NC; idx += NT) {  // ROWS_EP * NC is a multiple of NT: every lane runs every iteration
+      const int ml = idx / NC, m = mbase + ml;
+      const bool active = col_ok && m < p.M;
+      float s1 = 0.f, s2 = 0.f;
+      if (active) {
+        const f16x8 v = *(const f16x8*)(stg + ml * SLD + nc * 8);
+        float x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = (float)v[k] + bv[k];
+        if (fl & GF_RESID) {
+          const f16x8 r = *(const f16x8*)(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] += (float)r[k];
+        }
         f16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)a[e] + ba[e]) * gelu_erf((float)gt[e] + bg[e]));
-        *(f16x8*)((f16*)p.C + (size_t)m * p.ldc + (size_t)((n0 / 128 + g) * 64) + nc * 8) = o;
+        for (int k = 0; k < 8; ++k) {
+          o[k] = (f16)x[k];
+          const float f = (float)o[k];
+          s1 += f; s2 += f * f;
+        }
+        *(f16x8*)((f16*)p.C + (size_t)m * p.ldc + n) = o;
       }
-    }
-    return;
-  }
-  constexpr int NC = BN / 8;
-  const int nc = tid % NC, n = n0 + nc * 8;
-  const bool col_ok = (n + 8 <= p.N);
-  float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (col_ok && (fl & GF_BIAS)) {
+      if (fl & GF_ROWSTATS) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = p.bias[n + e];
-  }
-  for (int idx = tid; idx < BM * NC; idx += 256) {
-    const int ml = idx / NC, m = m0 + ml;
-    const bool active = col_ok && m < p.M;
-    float s1 = 0.f, s2 = 0.f;
-    if (active) {
-      const f16x8 v = *(const f16x8*)(stg + ml * SLD + nc * 8);
-      float x[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = (float)v[e] + bv[e];
-      if (fl & GF_RESID) {
-        const f16x8 r = *(const f16x8*)(p.R + (size_t)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] += (float)r[e];
-      }
-      f16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        o[e] = (f16)x[e];
-        const float f = (float)o[e];
-        s1 += f; s2 += f * f;
-      }
-      *(f16x8*)((f16*)p.C + (size_t)m * p.ldc + n) = o;
-    }
-    if (fl & GF_ROWSTATS) {
-#pragma unroll
-      for (int o = NC / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-      if (nc == 0 && m < p.M) {
-        p.st_out[((size_t)tile_n * st_rows + m) * 2] = s1;
-        p.st_out[((size_t)tile_n * st_rows + m) * 2 + 1] = s2;
+        for (int o = NC / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if (nc == 0 && m < p.M) {
+          p.st_out[((size_t)tile_n * st_rows + m) * 2] = s1;
+          p.st_out[((size_t)tile_n * st_rows + m) * 2 + 1] = s2;
+        }
       }
     }
   }
@@ -328,20 +399,20 @@ __global__ void amax_f16_kernel(const f16* __restrict__ w, int ldw, int K, int r
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WM, int WN>
 int launch_fp8(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   constexpr int lds = 2 * (BM + BN) * 128 + BM * 8;
-  static_assert(lds >= BM * (BN + 8) * 2, "staging tile must fit");
-  hipLaunchKernelGGL((gemm_fp8_kernel<BM, BN>), dim3(tiles), dim3(256), lds, s, p);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  hipLaunchKernelGGL((gemm_fp8_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(WM * WN * 64), lds, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
 }  // namespace
 
 void dtp_gemm_fp8_init() {
-#define SET_ATTR(BM, BN) (void)hipFuncSetAttribute((const void*)gemm_fp8_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * 128 + BM * 8);
-  SET_ATTR(128, 128) SET_ATTR(128, 64) SET_ATTR(64, 64) SET_ATTR(64, 128)
+#define SET_ATTR(BM, BN, WM, WN) (void)hipFuncSetAttribute((const void*)gemm_fp8_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * 128 + BM * 8);
+  SET_ATTR(128, 128, 2, 2) SET_ATTR(128, 64, 2, 2) SET_ATTR(64, 64, 2, 2) SET_ATTR(64, 128, 2, 2) SET_ATTR(256, 256, 2, 4)
 #undef SET_ATTR
 }
 
@@ -355,18 +426,19 @@ bool dtp_gemm_fp8_supported(const GemmParams& p) {
   return p.M > 0 && p.N > 0 && p.K > 0 && p.a_scale > 0.f && p.w_scale > 0.f;
 }
 
-// tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 64x128 (M x N), like the first four ids of dtp_launch_gemm
+// tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 64x128 (M x N), like the first four ids of dtp_launch_gemm; 4 = 256x256 (8 waves)
 int dtp_launch_gemm_fp8(const GemmParams& p, int tile, hipStream_t s) {
-  if (!dtp_gemm_fp8_supported(p) || tile < 0 || tile > 3 || ((p.flags & GF_GEGLU) && (tile == 1 || tile == 2))) {
+  if (!dtp_gemm_fp8_supported(p) || tile < 0 || tile > 4 || ((p.flags & GF_GEGLU) && (tile == 1 || tile == 2))) {
     dtp_set_error("gemm_fp8: unsupported problem / tile %d", tile);
     return DTP_ERR_ARG;
   }
   int rc;
   switch (tile) {
-    case 0: rc = launch_fp8<128, 128>(p, s); break;
-    case 1: rc = launch_fp8<128, 64>(p, s); break;
-    case 2: rc = launch_fp8<64, 64>(p, s); break;
-    default: rc = launch_fp8<64, 128>(p, s); break;
+    case 0: rc = launch_fp8<128, 128, 2, 2>(p, s); break;
+    case 1: rc = launch_fp8<128, 64, 2, 2>(p, s); break;
+    case 2: rc = launch_fp8<64, 64, 2, 2>(p, s); break;
+    case 3: rc = launch_fp8<64, 128, 2, 2>(p, s); break;
+    default: rc = launch_fp8<256, 256, 2, 4>(p, s); break;
   }
   if (rc != DTP_OK) dtp_set_error("gemm_fp8 launch failed: %s", hipGetErrorString(hipGetLastError()));
   return rc;

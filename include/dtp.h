@@ -161,7 +161,7 @@ typedef struct {
                         stages 2..4; 12..15 = conv_halo_kernel (8x16|8x8 pixel tile) x (64|128 channels), needs Wcb;
                         16..19 = gemm_kernel 256x128 (2|3 stages), 128x256 (2|3 stages);
                         20 / 21 = gemm_wide_kernel 256x256 / 256x320 (8 waves; unsplit, N % 8 == 0; 21: no GEGLU);
-                        24..27 = gemm_fp8_kernel 128x128 / 128x64 / 64x64 / 64x128 (needs W8; dense, unsplit) */
+                        24..28 = gemm_fp8_kernel 128x128 / 128x64 / 64x64 / 64x128 / 256x256 (8 waves) (needs W8; dense, unsplit) */
   int splits;        /* 0 = heuristic; >=1 = forced split-K factor */
   const float* lns;  /* DTP_GF_LNFOLD: row sums of the packed weights (dtp_op_rowsum) */
   float ln_eps;
@@ -178,7 +178,7 @@ typedef struct {
   const float* st_in;/* DTP_GF_LNFOLD: row statistics of A handed over by its producer ([st_parts][M][2]); NULL = computed in-kernel */
   int st_parts;
   int st_parts_out;  /* written by dtp_op_gemm: number of partials per row the chosen tile emitted into st_out */
-  const void* W8;    /* tile 24..27 (gemm_fp8_kernel, BASELINE configs[4]): e4m3 copy of the packed weights from dtp_op_quantize_w8,
+  const void* W8;    /* tile 24..28 (gemm_fp8_kernel, BASELINE configs[4]): e4m3 copy of the packed weights from dtp_op_quantize_w8,
                         [rows][ldw8] bytes, K padded to 128; with DTP_GF_LNFOLD the LayerNorm is applied while A is staged */
   int ldw8;
   float a_scale, w_scale; /* A8 = e4m3(A / a_scale), W8 = e4m3(W / w_scale) (powers of two); the product is applied to the accumulators */

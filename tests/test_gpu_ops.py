@@ -454,7 +454,7 @@ def _e4(t, scale=1.0):
 
 
 @pytest.mark.parametrize("m,n,k,tile", [(300, 320, 320, 24), (700, 640, 1280, 24), (130, 1280, 320, 26), (64, 768, 768, 27), (513, 320, 1280, 25),
-                                        (200, 320, 400, 26)])
+                                        (200, 320, 400, 26), (700, 640, 1280, 28), (300, 320, 320, 28)])
 def test_gemm_fp8(ops, m, n, k, tile):
     """fp8 (e4m3) GEMM on the MX MFMA (configs[4]): the products of e4m3 operands are exact in the fp32 accumulator, so against the
     same contraction on the e4m3-rounded operands only the summation order differs (2e-3); against exact fp32 it is the
@@ -492,6 +492,8 @@ def test_gemm_fp8_layernorm_geglu_and_two_operands(ops):
     wp = ops.pack_linear(wg.cuda(), geglu=True)
     w8, ws = ops.quantize_w8(wp, c)
     got = ops.gemm(x.cuda(), wp, 8 * c, c, bias=bp.cuda(), flags=GF_GEGLU | GF_BIAS, tile=24, w8=w8, w_scale=ws, layernorm=True)
+    wide = ops.gemm(x.cuda(), wp, 8 * c, c, bias=bp.cuda(), flags=GF_GEGLU | GF_BIAS, tile=28, w8=w8, w_scale=ws, layernorm=True)
+    assert (wide.float() - got.float()).abs().max().item() <= 2e-3 * got.float().abs().max().item() + 2e-3  # 8-wave tile: same operands
     xn = F.layer_norm(x.float(), (c,), None, None, 1e-5)
     h8 = F.linear(_e4(xn), _e4(wg, ws), b2)
     a8, g8 = h8.chunk(2, dim=-1)
@@ -508,7 +510,9 @@ def test_gemm_fp8_layernorm_geglu_and_two_operands(ops):
     res = rnd(m, n, seed=216)
     wp = ops.pack_linear(w.float().cuda())
     w8, ws = ops.quantize_w8(wp, k1 + k2)
+    got28 = ops.gemm(fa.cuda(), wp, n, k1, resid=res.cuda(), tail=rb.cuda(), tile=28, w8=w8, w_scale=ws)
     got, st = ops.gemm(fa.cuda(), wp, n, k1, resid=res.cuda(), tail=rb.cuda(), tile=26, w8=w8, w_scale=ws, row_stats=True)
+    assert (got28.float() - got.float()).abs().max().item() <= 2e-3 * got.float().abs().max().item() + 2e-3
     ref8 = F.linear(torch.cat([_e4(fa), _e4(rb)], dim=1), _e4(w, ws)) + res.float()
     close(got, ref8, tol=2e-3)
     tot = st.sum(dim=0).cpu()
