@@ -63,7 +63,7 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int ldx, float* __res
 
 // pass 2: every block first combines the per-chunk partials of its batch item into (mean, rstd) for all
 // groups (8 lanes per group, fixed order -> deterministic), then normalises (+ SiLU) 8-channel chunks.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy,
+__global__ __launch_bounds__(1024) void gn_apply_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ partial, int nchunk, int HW, int C, int cpg,
                                                         int groups, int silu, float inv_count, float eps) {
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
   const f16* xb = x + (size_t)b * HW * ldx;
   f16* yb = y + (size_t)b * HW * ldy;
 #pragma unroll 2
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long pix = i / nch;
     const int c0 = (int)(i - pix * nch) * 8;
     const f16x8 v = *(const f16x8*)(xb + (size_t)pix * ldx + c0);
@@ -420,10 +420,13 @@ int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* ga
   if (threads > 1024) { dtp_set_error("groupnorm: C too large"); return DTP_ERR_ARG; }
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(threads), 0, s, x, ldx, ws, HW, C, cpg, groups, ppc);
   const long long per_batch = (long long)HW * nch;
-  long long bx = (per_batch + 255) / 256;
-  const long long cap = std::max<long long>(1, 768 / B);  // every block re-reduces the partials of its batch item first
+  // one fat block per CU (tools/diag_gn.py sweep: 1024 threads x <= 256 blocks is 5-7 % ahead of 256 x 768): every block
+  // re-reduces the partials of its batch item first, so fewer blocks re-read them less often
+  const int at = 1024;
+  long long bx = (per_batch + at - 1) / at;
+  const long long cap = std::max<long long>(1, 256 / B);
   if (bx > cap) bx = cap;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((int)bx, B), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, ws, nchunk, HW, C, cpg,
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((int)bx, B), dim3(at), 0, s, x, ldx, y, ldy, gamma, beta, ws, nchunk, HW, C, cpg,
                      groups, silu, 1.0f / ((float)HW * cpg), eps);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
