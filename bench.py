@@ -51,6 +51,24 @@ def cpu_baseline(res, ddim_steps, weights, budget_note):
                       f"extrapolated to {ddim_steps - 1} evals + 2 encodes + 1 decode = {stamp_s:.1f}s/stamp; {budget_note}"}
 
 
+def cpu_config0():
+    """BASELINE configs[0] timed IN FULL on the host cores (SURVEY.md 8d "config 1 (N=4) timed fully"): one 512 x 512 stamp, 4 DDIM
+    steps = 3 UNet evaluations at batch 3 + 2 VAE encodes + 1 decode + the orchestration through the fp32 CPU oracle; about a
+    minute on a 128-thread host.  `python bench.py --cpu-config0 > profiles/rNN_cpu_config0.json`, once per round."""
+    from diffusiontexturepainting_amd import synthetic, weights as W
+    from oracle import nets, pipeline
+    merged = dict(unet=nets.merge_lora(W.synthetic_unet(), W.synthetic_lora()), vae=W.synthetic_vae())
+    canvas, brush, lat, eps = synthetic.make_stamp_batch(1, 512, seed=1000)
+    cond, uncond = synthetic.make_conditioning(7)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = pipeline.generate_raw(merged, brush, cond, uncond, canvas, lat, eps, steps=4, context_pad=150, tg_steps=4, cfg_weight=2.0, tg_weight=1.0)
+    dt = time.perf_counter() - t0
+    return {"config": "BASELINE.json configs[0]: 1 x 512x512, 4-step DDIM (3 UNet evaluations), fp32 torch CPU restatement (oracle/)",
+            "seconds_per_stamp": dt, "stamps_per_s": 1.0 / dt, "cores": torch.get_num_threads(), "kind": "port",
+            "finite": bool(torch.isfinite(out).all()), "torch": torch.__version__}
+
+
 def kernel_source_hash():
     """sha1 over the HIP sources + headers the library was built from: ties a PMC summary to the build it was collected on."""
     import hashlib
@@ -141,10 +159,14 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-config0", action="store_true", help="time BASELINE configs[0] in full on the host cores (CPU oracle) and exit")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra configurations (batch 8, 256 px, oracle pixel error)")
     ap.add_argument("--dump-launches", default="", help="CSV with one line per profiled kernel launch")
     a = ap.parse_args()
+    if a.cpu_config0:
+        print(json.dumps(cpu_config0()))
+        return
 
     from diffusiontexturepainting_amd import dist as D, synthetic, weights as W
     from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
