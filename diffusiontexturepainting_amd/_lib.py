@@ -29,7 +29,8 @@ PROF_KINDS = [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 
     ["attention_kernel", "groupnorm (gn_stats+gn_apply | gn_fused)", "layernorm_kernel", "concat_kernel / small elementwise",
      "softmax_rows_kernel", "conv_halo_kernel<8, 16, 64>", "conv_halo_kernel<8, 16, 128>", "conv_halo_kernel<8, 8, 64>",
      "conv_halo_kernel<8, 8, 128>", "gemm_kernel<256, 128, 2>", "gemm_kernel<256, 128, 3>", "gemm_kernel<128, 256, 2>",
-     "gemm_kernel<128, 256, 3>", "gemm_wide_kernel<256, 256>", "gemm_wide_kernel<256, 320>", "gemm_fp8_kernel"]
+     "gemm_kernel<128, 256, 3>", "gemm_wide_kernel<256, 256>", "gemm_wide_kernel<256, 320>", "gemm_fp8_kernel"] + \
+    [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 4}, 2>" for i in range(8)]
 
 
 class GemmDesc(C.Structure):

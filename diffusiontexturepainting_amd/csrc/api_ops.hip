@@ -89,8 +89,8 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
     p.kb_per_split = (p.nkb + d->splits - 1) / d->splits;
     p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
   }
-  if (tile >= 20) { p.splits = 1; p.kb_per_split = p.nkb; }  // the wide and fp8 tiles are unsplit
-  if ((tile >= 24) != (p.W8 != nullptr)) { dtp_set_error("gemm: tiles 24..27 and W8 go together"); return DTP_ERR_ARG; }
+  if (tile >= 20 && tile < 32) { p.splits = 1; p.kb_per_split = p.nkb; }  // the wide and fp8 tiles are unsplit
+  if ((tile >= 24 && tile < 32) != (p.W8 != nullptr)) { dtp_set_error("gemm: tiles 24..27 and W8 go together"); return DTP_ERR_ARG; }
   if (tile >= 12 && tile < 16) {  // halo-tiled 3x3 conv: split-K counts 64-channel blocks
     if (!d->Wcb) { dtp_set_error("conv_halo: Wcb missing"); return DTP_ERR_ARG; }
     p.W = (const f16*)d->Wcb;

@@ -411,9 +411,9 @@ static bool tune_entry_valid(const GemmParams& p, int tile, int sp) {
   if (halo) return p.Wcb && dtp_conv_halo_supported(p) && p.batch <= 1;
   int bm = 0, bn = 0, ns = 0;
   if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) return false;
-  if (tile >= 24) { GemmParams q = p; q.splits = 1; return sp == 1 && tile <= 28 && dtp_gemm_fp8_supported(q) && !((p.flags & GF_GEGLU) && (bn % 128)); }
+  if (tile >= 24 && tile < 32) { GemmParams q = p; q.splits = 1; return sp == 1 && tile <= 28 && dtp_gemm_fp8_supported(q) && !((p.flags & GF_GEGLU) && (bn % 128)); }
   if (p.W8) return false;
-  if (tile >= 20) { GemmParams q = p; q.splits = 1; return sp == 1 && dtp_gemm_wide_supported(q, tile - 20); }
+  if (tile >= 20 && tile < 32) { GemmParams q = p; q.splits = 1; return sp == 1 && dtp_gemm_wide_supported(q, tile - 20); }
   if ((p.flags & GF_GEGLU) && (bn != 128 || sp != 1)) return false;
   if (sp > 1 && ((p.flags & (GF_LNFOLD | GF_SOFTMAX16)) || p.batch > 1)) return false;
   if ((size_t)sp * p.M * p.N * sizeof(float) > ((size_t)512 << 20)) return false;
@@ -439,8 +439,8 @@ void tune_cache_save(Ctx* c) {
 // with every tile variant x split-K factor on the real buffers and the fastest pair is kept.
 static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   char key[200];
-  // "k4|": bump when tile ids or pipelines change, so that a persisted table written by an older build is ignored
-  int kl = snprintf(key, sizeof(key), "k4|%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
+  // "k5|": bump when tile ids or pipelines change, so that a persisted table written by an older build is ignored
+  int kl = snprintf(key, sizeof(key), "k5|%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
                     p.stride, p.lda, p.ldc, p.ldw, p.st_parts, p.Cin2, p.lda2);
   if (p.batch > 1) kl += snprintf(key + kl, sizeof(key) - kl, ",b%d", p.batch);
   if (p.W8) snprintf(key + kl, sizeof(key) - kl, ",f8");
@@ -494,11 +494,11 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     };
     struct Cand { float ms; int tile, sp; };
     std::vector<Cand> cands;
-    for (int tile = 0; tile < 29; ++tile) {  // 4 tile shapes x 3 pipeline depths, the 256-row / 256-column tiles, the 8-wave wide tiles, fp8
+    for (int tile = 0; tile < 40; ++tile) {  // 4 tile shapes x 3 pipeline depths, the 256-row / 256-column tiles, the 8-wave wide tiles, fp8, the 8-wave twins of the small shapes
       int bm = 0, bn = 0, ns = 0;
       if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) continue;
-      if ((p.W8 != nullptr) != (tile >= 24)) continue;  // an fp8 problem runs on the fp8 tiles only, and vice versa
-      if (tile >= 24) {
+      if ((p.W8 != nullptr) != (tile >= 24 && tile < 32)) continue;  // an fp8 problem runs on the fp8 tiles only, and vice versa
+      if (tile >= 24 && tile < 32) {
         if (geglu && (bn % 128)) continue;
         if (tile == 28 && (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) < 96) continue;
         float ms;
@@ -506,7 +506,7 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
         if (ms >= 0.f) cands.push_back({ms, tile, 1});
         continue;
       }
-      if (tile >= 20) {  // gemm_wide_kernel: unsplit big-M problems only (at least half a wave of 256 CUs worth of tiles)
+      if (tile >= 20 && tile < 32) {  // gemm_wide_kernel: unsplit big-M problems only (at least half a wave of 256 CUs worth of tiles)
         GemmParams q = p;
         q.splits = 1;
         if (!dtp_gemm_wide_supported(q, tile - 20)) continue;
@@ -620,7 +620,7 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
            p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? (p.W8 ? " geglu fp8" : " geglu") : (p.W8 ? " fp8" : ""), p.stride == 2 ? " s2" : "",
            p.batch > 1 ? (" x" + std::to_string(p.batch)).c_str() : "");
-  const int kind = tile >= 24 ? PK_FP8 : tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
+  const int kind = tile >= 32 ? PK_KH2 + tile - 32 : tile >= 24 ? PK_FP8 : tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
   const double flops = 2.0 * nb * p.M * (double)p.N * k_alg;
   prog_push(c, prog, kind, flops, bytes, make_gemm_op(c, p, tile, bias_step_off), lab);
   if (p.splits > 1) {  // a GroupNorm pushed next may take over the reduce (Builder::gn)

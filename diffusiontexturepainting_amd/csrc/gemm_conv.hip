@@ -32,8 +32,13 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 // NS = LDS pipeline depth: the DMA of k-block t+NS-1 is issued while k-block t is multiplied; the wait
 // before the (raw) barrier is a COUNTED vmcnt so NS-2 younger stages stay in flight across it.
-template <int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
+// KH = 2: EIGHT waves on the same tile (two per SIMD).  Waves 4-7 own the same four quadrants as waves 0-3 but multiply the
+// second half of every k-block (k-steps 2, 3), all eight share the DMA of a k-block (half the pieces each) and the two partial
+// accumulators are summed through LDS after the loop.  One 4-wave workgroup per CU fills its LDS at ~26 B/clk -- a wave issues an
+// LDS-DMA piece every ~130 cycles -- so the mid-size contractions of a batch-1 stamp (grids of <= 256 workgroups) are bound by
+// that; a second wave per SIMD doubles the issue rate without a second workgroup's fp32 split-K slab.
+template <int BM, int BN, int NS, int KH = 1>
+__global__ __launch_bounds__(256 * KH) void gemm_kernel(const GemmParams pin) {
   GemmParams p = pin;
   const int st_rows = p.st_rows > 0 ? p.st_rows : p.M;
   const int st_m0 = (p.batch > 1) ? (int)blockIdx.y * p.M : 0;
@@ -46,13 +51,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
     if (p.lns) p.lns += bz * p.lns_bs;
   }
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA blocks per wave along M / N
-  constexpr int AR = BM / 32, WR = BN / 32;  // DMA wave-instructions per wave per k-block
+  constexpr int NT = 256 * KH, RPR = 32 * KH;  // threads; LDS rows filled by one DMA round of all waves
+  constexpr int KS = 4 / KH;                   // k-steps of a k-block multiplied by one wave
+  constexpr int AR = BM / RPR, WR = BN / RPR;  // DMA wave-instructions per wave per k-block
+  static_assert(BM % RPR == 0 && BN % RPR == 0 && (KH == 1 || KH == 2), "tile / wave grid mismatch");
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int SLD = BN + 8;                // staging-tile row stride (f16)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = wave & 3, kh = wave >> 2;  // quadrant of the tile / half of the k-block this wave multiplies
 
   // ---- XCD-aware tile assignment (bijective remap; block b runs on XCD b % 8)
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
   const int kb0 = blockIdx.z * p.kb_per_split;
   const int nk = min(p.kb_per_split, p.nkb - kb0);
 
-  // ---- DMA source state.  Row r = i*32 + wave*8 + (lane>>3); LDS slot = lane&7 holds source
+  // ---- DMA source state.  Row r = i*RPR + wave*8 + (lane>>3); LDS slot = lane&7 holds source
   // chunk slot ^ ((r>>1)&7).
   const int lrow = wave * 8 + (lane >> 3);
   const int kc = (((lane & 7) ^ ((lrow >> 1) & 7)) << 3);  // element offset inside the k-block
@@ -81,7 +90,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
   int a_pix[AR], a_y[AR], a_x[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    const int m = m0 + i * 32 + lrow;
+    const int m = m0 + i * RPR + lrow;
     if (conv) {
       const int hw = p.Ho * p.Wo;
       const int b = m / hw, rem = m - b * hw;
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
   const f16* w_row[WR];
 #pragma unroll
   for (int i = 0; i < WR; ++i) {  // packed weights have ceil(N/128)*128 rows: a 256-wide tile may reach past them
-    const int n = n0 + i * 32 + lrow;
+    const int n = n0 + i * RPR + lrow;
     w_row[i] = (BN <= 128 || n < ((p.N + 127) & ~127)) ? p.W + (size_t)n * p.ldw + kc : nullptr;
   }
 
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
         } else {  // dense tail: output pixel m reads row m of the shortcut input
 #pragma unroll
           for (int i = 0; i < AR; ++i) {
-            const int m = m0 + i * 32 + lrow;
+            const int m = m0 + i * RPR + lrow;
             a_row[i] = (tap == 9 && p.A2 && m < p.M) ? p.A2 + (size_t)m * p.lda2 : nullptr;
           }
         }
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
         dense_tail = true;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-          const int m = m0 + i * 32 + lrow;
+          const int m = m0 + i * RPR + lrow;
           a_row[i] = (m < p.M) ? p.A2 + (size_t)m * p.lda2 + kc : nullptr;
         }
       }
@@ -157,8 +166,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
   };
   auto piece = [&](int stage, int q) {
     char* As = smem + stage * STAGE;
-    if (q < AR) glds16(a_row[q] ? a_row[q] + a_off : p.zero, As + (q * 32 + wave * 8) * 128);
-    else glds16((BN <= 128 || w_row[q - AR]) ? w_row[q - AR] + w_off : p.zero, As + BM * 128 + ((q - AR) * 32 + wave * 8) * 128);
+    if (q < AR) glds16(a_row[q] ? a_row[q] + a_off : p.zero, As + (q * RPR + wave * 8) * 128);
+    else glds16((BN <= 128 || w_row[q - AR]) ? w_row[q - AR] + w_off : p.zero, As + BM * 128 + ((q - AR) * RPR + wave * 8) * 128);
   };
   auto issue = [&](int stage, int kb) {
     prep(kb);
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int wn0 = (wave & 1) * (BN / 2), wm0 = (wave >> 1) * (BM / 2);
+  const int wn0 = (wq & 1) * (BN / 2), wm0 = (wq >> 1) * (BM / 2);
   const int frow = lane & 31, fhalf = lane >> 5;
 
   constexpr int LOADS = AR + WR;  // DMA instructions per wave per stage
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
   float* rowst = (float*)(smem + NS * STAGE);
   if ((p.flags & GF_LNFOLD) && p.st_in) {
     // statistics were emitted by the producer of A (GF_ROWSTATS): combine its per-N-tile partials
-    for (int r = tid; r < BM; r += 256) {
+    for (int r = tid; r < BM; r += NT) {
       const int m = m0 + r;
       float s1 = 0.f, s2 = 0.f;
       if (m < p.M)
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
     }
   } else if (p.flags & GF_LNFOLD) {
     const int l16 = tid & 15, nch = p.K >> 3;
-    for (int r0 = 0; r0 < BM; r0 += 16) {
+    for (int r0 = 0; r0 < BM; r0 += NT / 16) {
       const int r = r0 + (tid >> 4), m = m0 + r;
       float s1 = 0.f, s2 = 0.f;
       if (m < p.M) {
@@ -232,11 +241,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
     const char* As = smem + cur * STAGE;
     const char* Ws = As + BM * 128;
     // fragments of k-step ks live in fr[ks % LA]: [0,TM) activations, [TM,TM+TN) weights; LA k-steps are in flight
-    constexpr int NF = TM + TN, LA = (4 * NF <= 16) ? 4 : 2, PPS = (NP + 3) / 4;
+    constexpr int NF = TM + TN, LA = (4 * NF <= 16 && KS == 4) ? 4 : 2, PPS = (NP + KS - 1) / KS;
     f16x8 fr[LA][NF];
+    const int ks0 = kh * KS;  // first k-step of this wave's share
     const uint32_t a_lds = lds_addr(As), w_lds = lds_addr(Ws);
     auto read_step = [&](int ks) {
-      const int c = ks * 2 + fhalf;
+      const int c = (ks0 + ks) * 2 + fhalf;
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int row = wm0 + j * 32 + frow;
@@ -267,19 +277,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
 #define DTP_MMA_STEP(ks)                                                                                    \
     {                                                                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
-      wait_lds_frags<((ks + LA < 4 ? ks + LA : 4) - ks - 1) * NF, NF>(fr[ks % LA]);                         \
+      wait_lds_frags<((ks + LA < KS ? ks + LA : KS) - ks - 1) * NF, NF>(fr[ks % LA]);                       \
       _Pragma("unroll") for (int i = 0; i < TN; ++i) _Pragma("unroll") for (int j = 0; j < TM; ++j) {       \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[ks % LA][TM + i], fr[ks % LA][j], acc[i][j], 0, 0, 0); \
         if constexpr (PPS >= 1) { if (i * TM + j == 0) { DTP_PIECE(ks * PPS) } }                            \
         if constexpr (PPS >= 2) { if (i * TM + j == NM / PPS) { DTP_PIECE(ks * PPS + 1) } }                 \
         if constexpr (PPS >= 3) { if (i * TM + j == 2 * NM / PPS) { DTP_PIECE(ks * PPS + 2) } }             \
       }                                                                                                     \
-      if constexpr (ks + LA < 4) {                                                                          \
+      if constexpr (ks + LA < KS) {                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         read_step(ks + LA);                                                                                 \
       }                                                                                                     \
     }
-    DTP_MMA_STEP(0) DTP_MMA_STEP(1) DTP_MMA_STEP(2) DTP_MMA_STEP(3)
+    DTP_MMA_STEP(0) DTP_MMA_STEP(1)
+    if constexpr (KS == 4) { DTP_MMA_STEP(2) DTP_MMA_STEP(3) }
 #undef DTP_MMA_STEP
 #undef DTP_PIECE
   };
@@ -304,8 +315,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
   run(std::false_type{}, t_steady, nk);
 
   // ---------------------------------------------------------------- epilogue
+  if constexpr (KH == 2) {  // sum the two k-halves: waves 4-7 hand their accumulators to waves 0-3 through the (now free) stages
+    static_assert(BM * BN * 4 <= NS * STAGE, "the fp32 exchange tile must fit in the pipeline buffers");
+    float* red = (float*)smem;
+    __syncthreads();  // every wave finished reading the last stage
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *(f32x4*)(red + ((((i * TM + j) * 4 + q) * 4 + wq) * 64 + lane) * 4) = v;
+          }
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *(const f32x4*)(red + ((((i * TM + j) * 4 + q) * 4 + wq) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[e];
+          }
+    }
+  }
   // D layout (32x32): lane holds column (lane&31) = token, rows (r&3)+8*(r>>2)+4*(lane>>5) = channel.
   if (p.splits > 1) {
+    if (kh != 0) return;
     float* part = p.part + (size_t)blockIdx.z * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -330,8 +371,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
     return;
   }
 
-  __syncthreads();  // all waves finished reading the last stage before it is reused as staging
+  __syncthreads();  // all waves finished reading the last stage (KH = 2: the exchange tile) before it is reused as staging
   f16* stg = (f16*)smem;
+  if (kh == 0)
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -367,7 +409,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { la[e] = t0[e]; la[4 + e] = t1[e]; lg[e] = u0[e]; lg[4 + e] = u1[e]; }
     }
-    for (int idx = tid; idx < BM * HC; idx += 256) {
+    for (int idx = tid; idx < BM * HC; idx += NT) {
       const int ml = idx / HC;
       const int m = m0 + ml;
       if (m >= p.M) continue;
@@ -411,7 +453,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
       if (fl & GF_LNFOLD) lv[e] = p.lns[n + e];
     }
   }
-  for (int idx = tid; idx < BM * NC; idx += 256) {  // BM*NC is a multiple of 256: every lane runs every iteration
+  static_assert((BM * NC) % NT == 0 && NT % NC == 0, "every lane runs every iteration and keeps its column chunk");
+  for (int idx = tid; idx < BM * NC; idx += NT) {
     const int ml = idx / NC;
     const int m = m0 + ml;
     const bool active = (m < p.M) && (n < p.N);
@@ -542,13 +585,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
   if (lane == 0) { p.st_out[(size_t)m * 2] = s1; p.st_out[(size_t)m * 2 + 1] = s2; }
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int KH = 1>
 int launch_tile(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   constexpr int lds = NS * (BM + BN) * 128 + BM * 8;  // + per-row LayerNorm statistics
   static_assert(lds - BM * 8 >= BM * (BN + 8) * 2, "staging tile must fit in the pipeline buffers");
   static_assert(lds <= 160 * 1024, "LDS budget");
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS>), dim3(tiles, p.batch > 1 ? p.batch : 1, p.splits), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS, KH>), dim3(tiles, p.batch > 1 ? p.batch : 1, p.splits), dim3(256 * KH), lds, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
@@ -558,12 +601,19 @@ int launch_tile(const GemmParams& p, hipStream_t s) {
   X(128, 128, 2) X(128, 128, 3) X(128, 128, 4) X(128, 64, 2) X(128, 64, 3) X(128, 64, 4) \
   X(64, 64, 2) X(64, 64, 3) X(64, 64, 4) X(64, 128, 2) X(64, 128, 3) X(64, 128, 4) \
   X(256, 128, 2) X(256, 128, 3) X(128, 256, 2) X(128, 256, 3)
+// the 8-wave (KH = 2) twins of the four small shapes at depth 2 and 3: tile ids 32..39
+#define FOR_ALL_KH2(X) \
+  X(128, 128, 2) X(128, 128, 3) X(128, 64, 2) X(128, 64, 3) X(64, 64, 2) X(64, 64, 3) X(64, 128, 2) X(64, 128, 3)
 
 void dtp_gemm_init() {  // raise the dynamic-LDS limit once, outside any stream capture
 #define SET_ATTR(BM, BN, NS) \
   (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8);
   FOR_ALL_VARIANTS(SET_ATTR)
 #undef SET_ATTR
+#define SET_ATTR2(BM, BN, NS) \
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8);
+  FOR_ALL_KH2(SET_ATTR2)
+#undef SET_ATTR2
 }
 
 // 20 / 21: gemm_wide_kernel 256 x 256 / 256 x 320 (gemm_wide.hip).  24..27: gemm_fp8_kernel, the shapes of ids 0..3 (gemm_fp8.hip).
@@ -576,6 +626,7 @@ bool dtp_gemm_tile_dims(int tile, int* bm, int* bn, int* ns) {
   if (tile == 20 || tile == 21) { *bm = 256; *bn = tile == 20 ? 256 : 320; *ns = 2; return true; }  // gemm_wide_kernel (8 waves)
   if (tile >= 24 && tile < 28) { *bm = sm[tile & 3]; *bn = sn[tile & 3]; *ns = 2; return true; }     // gemm_fp8_kernel
   if (tile == 28) { *bm = 256; *bn = 256; *ns = 2; return true; }                                    // gemm_fp8_kernel, 8 waves
+  if (tile >= 32 && tile < 40) { *bm = sm[tile & 3]; *bn = sn[tile & 3]; *ns = 2 + ((tile - 32) >> 2); return true; }  // gemm_kernel, 8 waves (KH = 2)
   return false;
 }
 
@@ -647,8 +698,12 @@ int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
   int rc = -1;
 #define DISPATCH(BM, BN, NS) \
   if (rc < 0 && bm == BM && bn == BN && ns == NS) rc = launch_tile<BM, BN, NS>(p, s);
-  FOR_ALL_VARIANTS(DISPATCH)
+  if (tile < 32) { FOR_ALL_VARIANTS(DISPATCH) }
 #undef DISPATCH
+#define DISPATCH2(BM, BN, NS) \
+  if (rc < 0 && bm == BM && bn == BN && ns == NS) rc = launch_tile<BM, BN, NS, 2>(p, s);
+  if (tile >= 32) { FOR_ALL_KH2(DISPATCH2) }
+#undef DISPATCH2
   if (rc != DTP_OK) { dtp_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
   if (p.splits > 1 && !(p.flags & GF_NOREDUCE)) return dtp_launch_splitk_reduce(p, s);
   return DTP_OK;

@@ -124,7 +124,8 @@ int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes);
  * 128x128 / 128x64 / 64x64 / 64x128), 12 = attention_kernel, 13 = GroupNorm (stats+apply or fused),
  * 14 = layernorm, 15 = concat/elementwise, 16 = softmax_rows, 17-20 = conv_halo_kernel<8,16,64> / <8,16,128> / <8,8,64> /
  * <8,8,128> (halo-tiled 3x3 conv), 21-24 = gemm_kernel<256,128,2> / <256,128,3> / <128,256,2> / <128,256,3>,
- * 25-26 = gemm_wide_kernel<256,256> / <256,320> (8-wave wide tiles), 27 = gemm_fp8_kernel (all four tiles).  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
+ * 25-26 = gemm_wide_kernel<256,256> / <256,320> (8-wave wide tiles), 27 = gemm_fp8_kernel (all tiles),
+ * 28-35 = gemm_kernel<BM,BN,NS,2> (the 8-wave twins of shapes 0..3 at 2 / 3 stages).  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
  * dtp_profile(ctx, 0) switches back to graph replay.  The nvtx/cudaEvent hooks of
  * stable_diffusion_pipeline.py:146-149,486-503 are the reference counterpart. */
 typedef struct { int kind; int launches; double ms; double flops; double bytes; } dtp_prof_row;
@@ -161,7 +162,9 @@ typedef struct {
                         stages 2..4; 12..15 = conv_halo_kernel (8x16|8x8 pixel tile) x (64|128 channels), needs Wcb;
                         16..19 = gemm_kernel 256x128 (2|3 stages), 128x256 (2|3 stages);
                         20 / 21 = gemm_wide_kernel 256x256 / 256x320 (8 waves; unsplit, N % 8 == 0; 21: no GEGLU);
-                        24..28 = gemm_fp8_kernel 128x128 / 128x64 / 64x64 / 64x128 / 256x256 (8 waves) (needs W8; dense, unsplit) */
+                        24..28 = gemm_fp8_kernel 128x128 / 128x64 / 64x64 / 64x128 / 256x256 (8 waves) (needs W8; dense, unsplit);
+                        32..39 = gemm_kernel with EIGHT waves on shape (id & 3), 2 + (id - 32) / 4 stages: waves 4-7 multiply the
+                        second half of every k-block and the halves are summed through LDS (same features as ids 0..11) */
   int splits;        /* 0 = heuristic; >=1 = forced split-K factor */
   const float* lns;  /* DTP_GF_LNFOLD: row sums of the packed weights (dtp_op_rowsum) */
   float ln_eps;
