@@ -386,7 +386,7 @@ static void tune_read_file(Ctx* c, const char* path) {
   char key[256];
   int tile, splits;
   while (fscanf(f, "%255s %d %d", key, &tile, &splits) == 3)
-    if (tile >= 0 && tile < 32 && splits >= 1 && splits <= 64) c->tuned[key] = std::make_pair(tile, splits);
+    if (tile >= 0 && tile < 40 && splits >= 1 && splits <= 64) c->tuned[key] = std::make_pair(tile, splits);  // shape-level checks: tune_entry_valid()
   fclose(f);
 }
 

@@ -354,3 +354,36 @@ def test_server_batches_two_real_clients(env):
         known = canv[cid][..., 3] == 255
         assert np.array_equal(rep["image"][known], canv[cid][..., :3][known])  # painted pixels come back bit-exact
     srv.close()
+
+
+def test_tune_table_roundtrip_and_tampering(tmp_path, sd, monkeypatch):
+    """The autotuner's table: what one context measured and saved, the next context must read back COMPLETELY (no shape tuned
+    twice, bit-identical stamps -- the seed shipped with the package rests on this), and a table whose entries do not fit their
+    shapes (halo tiles without the packing they need, split LayerNorm folds) must be ignored entry by entry, not trusted."""
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    cache = tmp_path / "tune.txt"
+    monkeypatch.setenv("DTP_TUNE_CACHE", str(cache))
+    monkeypatch.setenv("DTP_TUNE_SEED", str(tmp_path / "no_seed.txt"))
+    canvas, brush, cond, uncond, lat, eps = _inputs(1, R, 970)
+    st = dict(steps=3, context_pad=5, tg_steps=3)
+
+    def stamp():
+        m = MI355ConditionalInpainter(R, device=0, weights=sd, max_batch=1)
+        m.set_conditioning(cond, uncond, brush)
+        out = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st).cpu()
+        m._lib.dtp_destroy(m._h)
+        m._h = None
+        return out
+
+    out1 = stamp()
+    table1 = cache.read_text()
+    rows = [ln.split() for ln in table1.splitlines()]
+    assert len(rows) >= 20 and all(len(r) == 3 and r[0].startswith("k5|") for r in rows)
+    out2 = stamp()
+    assert cache.read_text() == table1          # nothing was tuned again: every saved entry was read back and accepted
+    assert torch.equal(out1, out2)
+    # every entry rewritten to a halo tile with a 7-way split: invalid for the dense shapes and the LayerNorm folds, and for the
+    # convs whose k-block count it does not divide into >= 9-block slices -- whatever survives validation must still be correct
+    cache.write_text("".join(f"{r[0]} 13 7\n" for r in rows))
+    out3 = stamp()
+    assert torch.isfinite(out3).all() and (out3 - out1).abs().max().item() <= 5e-3  # other tiles / splits: other fp16 roundings
