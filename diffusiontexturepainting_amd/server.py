@@ -117,9 +117,18 @@ class StampQueue:
         return job
 
     def close(self):
+        """Stop the worker; requests that were still queued are failed (logged, error frame if enabled) instead of being left
+        with waiters that never wake up."""
         self.stopping = True
         self.q.put(None)
         self.worker.join(timeout=30)
+        while True:
+            try:
+                job = self.q.get_nowait()
+            except queue.Empty:
+                break
+            if job is not None:
+                self._fail(job, RuntimeError("server is shutting down"))
 
     # ---- worker
     def _fail(self, job, exc):
@@ -166,8 +175,11 @@ class StampQueue:
     def _run(self):
         while True:
             job = self.q.get()
-            if job is None or self.stopping:
+            if job is None:
                 return
+            if self.stopping:  # close() was called while this request waited: answer it, do not run it
+                self._fail(job, RuntimeError("server is shutting down"))
+                continue
             if job.kind == "brush":
                 self._run_brush(job)
                 continue

@@ -143,3 +143,20 @@ def test_clients_are_routed_to_the_least_loaded_replica_and_stay_there():
     srv.on_message("new", _brush_msg((1, 2, 3)), sink.append, wait=True)
     assert sorted([srv.queues[0].load(), srv.queues[1].load()]) == [3, 3]  # the freed place was reused
     srv.close()
+
+
+def test_close_fails_the_requests_that_were_still_queued():
+    """Shutting a replica down must not leave a client waiting for ever (the very thing the error frame exists for)."""
+    model = FakeModel(delay=0.3)
+    srv = S.StampServer([model], max_batch=1, error_replies=True, gather_window_s=0.0)
+    replies = {c: [] for c in "abc"}
+    srv.on_message("a", _brush_msg((200, 10, 10)), replies["a"].append, wait=True)
+    jobs = [srv.on_message(c, _stamp_msg(), replies[c].append) for c in "abc"]  # the first runs for 0.3 s, the others wait behind it
+    time.sleep(0.05)
+    srv.close()
+    assert all(j.done.wait(timeout=5) for j in jobs)
+    failed = [j for j in jobs if j.error]
+    assert failed and all("shutting down" in j.error for j in failed)
+    for c, j in zip("abc", jobs):
+        if j.error:
+            assert replies[c][-1][0] == S.RETURN_ERROR and "shutting down" in S.decode_error_response(replies[c][-1])
