@@ -64,7 +64,7 @@ def torch_to_np(img):
 
 @dataclass
 class _Job:
-    kind: str                      # "brush" | "stamp"
+    kind: str                      # "brush" | "stamp" | "release" (the slot goes back to the pool)
     slot: int
     settings: dict
     payload: object                # brush image [3,H,W] f32 / canvas [4,R,R] f32
@@ -103,10 +103,12 @@ class StampQueue:
             return self.clients[client_id]
 
     def detach(self, client_id):
+        """The client is gone.  Its slot returns to the pool in QUEUE order, i.e. after the requests it still has in flight: a new
+        client that is handed the slot at once would otherwise re-encode it under a stamp that is still waiting for it."""
         with self.lock:
             slot = self.clients.pop(client_id, None)
-            if slot is not None:
-                self.free_slots.append(slot)
+        if slot is not None:
+            self.q.put(_Job("release", slot, {}, None, lambda _b: None))
 
     def load(self):
         with self.lock:
@@ -180,6 +182,11 @@ class StampQueue:
             if self.stopping:  # close() was called while this request waited: answer it, do not run it
                 self._fail(job, RuntimeError("server is shutting down"))
                 continue
+            if job.kind == "release":
+                with self.lock:
+                    self.free_slots.append(job.slot)
+                job.done.set()
+                continue
             if job.kind == "brush":
                 self._run_brush(job)
                 continue
@@ -195,8 +202,8 @@ class StampQueue:
                     if nxt.kind == "stamp" and _settings_key(nxt.settings) == _settings_key(job.settings):
                         pending.append(nxt)
                     else:
-                        held.append(nxt)   # a brush change or other settings: next round, order among those preserved
-                        if nxt.kind == "brush":
+                        held.append(nxt)   # a brush change, a slot release or other settings: next round, order among those preserved
+                        if nxt.kind != "stamp":
                             break
             except queue.Empty:
                 pass
@@ -204,6 +211,10 @@ class StampQueue:
             for h in held:
                 if h.kind == "brush":
                     self._run_brush(h)
+                elif h.kind == "release":
+                    with self.lock:
+                        self.free_slots.append(h.slot)
+                    h.done.set()
                 else:
                     self.q.put(h)
 

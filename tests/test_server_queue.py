@@ -160,3 +160,19 @@ def test_close_fails_the_requests_that_were_still_queued():
     for c, j in zip("abc", jobs):
         if j.error:
             assert replies[c][-1][0] == S.RETURN_ERROR and "shutting down" in S.decode_error_response(replies[c][-1])
+
+
+def test_a_departed_clients_slot_is_recycled_only_after_its_pending_stamp():
+    model = FakeModel(delay=0.15)
+    srv = S.StampServer([model], max_batch=1, gather_window_s=0.0)
+    out = {"a": [], "b": []}
+    srv.on_message("a", _brush_msg((250, 0, 0)), out["a"].append, wait=True)
+    blocker = srv.on_message("a", _stamp_msg(), out["a"].append)      # keeps the worker busy
+    srv.on_message("a", _stamp_msg(cfg=3.0), out["a"].append)         # a's second stamp waits in the queue ...
+    srv.close_client("a")                                             # ... when a disconnects
+    j = srv.on_message("b", _brush_msg((0, 0, 250)), out["b"].append, wait=True)  # b must not be given a's slot under that stamp
+    assert j.error is None and blocker.done.wait(5)
+    srv.close()
+    # a's queued stamp (cfg 3) ran with a's red brush, not with the blue one b brought: b got ANOTHER slot or came after it
+    img = sio.decode_response(out["a"][-1])["image"].astype(np.float32)
+    assert len(out["a"]) == 3 and img[..., 0].mean() > 10 * max(img[..., 2].mean(), 1e-3)
