@@ -136,7 +136,7 @@ def extra_measurements(model512, sd):
     out["configs[4]_256px_8steps_fp8"] = {
         "stamps_per_s": 1e3 / ms, "ms_per_stamp": ms, "timed_stamps": 5,
         "dtype": "f8e4m3 (self-attention QK^T / PV and the transformer Linears / 1x1 convs on the MX MFMA) + f16 (3x3 convs, norms, VAE)",
-        "note": "latency-bound at batch 1 (192-workgroup launches, operand conversion on the critical path): fp8 costs time here"}
+        "note": "latency-bound at batch 1: the autotuner keeps the fp16 kernel for the contractions (M < 6144) where the fp8 one is slower, so fp8 here = attention + the Linears it wins on"}
     del m256f8
     m64 = MI355ConditionalInpainter(64, device=model512._index, weights=sd, max_batch=2)
     canvas, brush, lat, eps = synthetic.make_stamp_batch(2, 64, seed=2300)

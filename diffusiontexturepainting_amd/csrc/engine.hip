@@ -412,7 +412,6 @@ static bool tune_entry_valid(const GemmParams& p, int tile, int sp) {
   int bm = 0, bn = 0, ns = 0;
   if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) return false;
   if (tile >= 24 && tile < 32) { GemmParams q = p; q.splits = 1; return sp == 1 && tile <= 28 && dtp_gemm_fp8_supported(q) && !((p.flags & GF_GEGLU) && (bn % 128)); }
-  if (p.W8) return false;
   if (tile >= 20 && tile < 32) { GemmParams q = p; q.splits = 1; return sp == 1 && dtp_gemm_wide_supported(q, tile - 20); }
   if ((p.flags & GF_GEGLU) && (bn != 128 || sp != 1)) return false;
   if (sp > 1 && ((p.flags & (GF_LNFOLD | GF_SOFTMAX16)) || p.batch > 1)) return false;
@@ -497,7 +496,12 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     for (int tile = 0; tile < 40; ++tile) {  // 4 tile shapes x 3 pipeline depths, the 256-row / 256-column tiles, the 8-wave wide tiles, fp8, the 8-wave twins of the small shapes
       int bm = 0, bn = 0, ns = 0;
       if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) continue;
-      if ((p.W8 != nullptr) != (tile >= 24 && tile < 32)) continue;  // an fp8 problem runs on the fp8 tiles only, and vice versa
+      // fp8 tiles need the e4m3 weight copy.  An fp8 problem keeps the choice of an fp16 tile while it is small (the register-
+      // staged activation operand costs latency-bound launches more than the MX MFMA returns: 256^2 / 8 steps 32.6 -> 27.5 ms);
+      // from M = 6144 on (every level-0..2 Linear of a batch-8 stamp) it runs on the fp8 tiles only -- there the cold single-launch
+      // timing of the tuner under-rates them (batch 8: 588 ms with fp8 tiles throughout, 606 ms with the tuner's mix, 605 ms in fp16)
+      const bool f8t = tile >= 24 && tile < 32;
+      if (f8t ? !p.W8 : (p.W8 && p.M >= 6144)) continue;
       if (tile >= 24 && tile < 32) {
         if (geglu && (bn % 128)) continue;
         if (tile == 28 && (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) < 96) continue;
@@ -617,8 +621,9 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   const double nb = p.batch > 1 ? (double)p.batch : 1.0;
   const double bytes = 2.0 * nb * (a_elems + (double)p.N * k_alg + (double)p.M * n_out);
   char lab[160];
+  const bool f8tile = tile >= 24 && tile < 32;  // an fp8 problem may have kept an fp16 tile (tune_gemm)
   snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
-           p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? (p.W8 ? " geglu fp8" : " geglu") : (p.W8 ? " fp8" : ""), p.stride == 2 ? " s2" : "",
+           p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? (f8tile ? " geglu fp8" : " geglu") : (f8tile ? " fp8" : ""), p.stride == 2 ? " s2" : "",
            p.batch > 1 ? (" x" + std::to_string(p.batch)).c_str() : "");
   const int kind = tile >= 32 ? PK_KH2 + tile - 32 : tile >= 24 ? PK_FP8 : tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
   const double flops = 2.0 * nb * p.M * (double)p.N * k_alg;
