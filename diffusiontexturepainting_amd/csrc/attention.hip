@@ -32,8 +32,10 @@
 
 namespace {
 
-template <int DP, bool SHIFT = false>  // SHIFT: d = 40 in a 48-wide contraction (see the header comment)
-__global__ __launch_bounds__(256, (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1))) void attention_kernel(const AttnParams p) {
+// OCC4: compile for four waves per SIMD (128 registers instead of 130): 4.7 % faster on the batched level-0 launch (6144
+// workgroups: 922 -> 879 us), 2 % slower when the whole grid is co-resident at three anyway (768 workgroups at batch 1)
+template <int DP, bool SHIFT = false, bool OCC4 = false>  // SHIFT: d = 40 in a 48-wide contraction (see the header comment)
+__global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)))) void attention_kernel(const AttnParams p) {
   static_assert(!SHIFT || DP == 48, "the shift column lives in the padding of d = 40");
   constexpr int KS = DP / 16;           // k-steps of the QK^T contraction
   constexpr int DB = (DP + 31) / 32;    // 32-row blocks of O^T
@@ -313,7 +315,14 @@ int dtp_launch_attention(const AttnParams& p, hipStream_t s) {
     return DTP_ERR_ARG;
   }
   dim3 grid((p.Sq + 127) / 128, p.H, p.B), block(256);
-  if (p.D == 40) hipLaunchKernelGGL((attention_kernel<48, true>), grid, block, 0, s, p);
+  static const int cus = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }();
+  const bool many = (long long)grid.x * grid.y * grid.z > 3LL * cus;  // more workgroups than fit at three waves per SIMD
+  if (p.D == 40 && many) hipLaunchKernelGGL((attention_kernel<48, true, true>), grid, block, 0, s, p);
+  else if (p.D == 40) hipLaunchKernelGGL((attention_kernel<48, true>), grid, block, 0, s, p);
   else if (p.D <= 48) hipLaunchKernelGGL((attention_kernel<48>), grid, block, 0, s, p);
   else if (p.D <= 64) hipLaunchKernelGGL((attention_kernel<64>), grid, block, 0, s, p);
   else if (p.D <= 80) hipLaunchKernelGGL((attention_kernel<80>), grid, block, 0, s, p);
