@@ -7,5 +7,5 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCL
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $grp --output-format csv -d /tmp/pmcm_$i -o p -- python /root/repo/tools/pmc_unet.py > /tmp/pmcm_$i.log 2>&1
   f=$(find /tmp/pmcm_$i -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then python /root/repo/tools/pmc_agg.py $f /root/repo/gpurun_out/r01_pmc_unet_mfma_$i.csv; else tail -5 /tmp/pmcm_$i.log > /root/repo/gpurun_out/r01_pmc_unet_mfma_$i.err; fi
+  if [ -n "$f" ]; then python /root/repo/tools/pmc_agg.py $f /root/repo/gpurun_out/r02_pmc_unet_mfma_$i.csv; else tail -5 /tmp/pmcm_$i.log > /root/repo/gpurun_out/r02_pmc_unet_mfma_$i.err; fi
 done
