@@ -415,7 +415,7 @@ static bool tune_entry_valid(const GemmParams& p, int tile, int sp) {
   if (tile >= 20 && tile < 32) { GemmParams q = p; q.splits = 1; return sp == 1 && dtp_gemm_wide_supported(q, tile - 20); }
   if ((p.flags & GF_GEGLU) && (bn != 128 || sp != 1)) return false;
   if (sp > 1 && ((p.flags & (GF_LNFOLD | GF_SOFTMAX16)) || p.batch > 1)) return false;
-  if ((size_t)sp * p.M * p.N * sizeof(float) > ((size_t)512 << 20)) return false;
+  if (sp > 1 && (size_t)sp * p.M * p.N * sizeof(float) > ((size_t)512 << 20)) return false;  // the fp32 slabs of a split
   return true;
 }
 

@@ -356,7 +356,7 @@ def test_server_batches_two_real_clients(env):
     srv.close()
 
 
-def test_tune_table_roundtrip_and_tampering(tmp_path, sd, monkeypatch):
+def test_tune_table_roundtrip_and_tampering(tmp_path, sd, monkeypatch, capfd):
     """The autotuner's table: what one context measured and saved, the next context must read back COMPLETELY (no shape tuned
     twice, bit-identical stamps -- the seed shipped with the package rests on this), and a table whose entries do not fit their
     shapes (halo tiles without the packing they need, split LayerNorm folds) must be ignored entry by entry, not trusted."""
@@ -379,8 +379,10 @@ def test_tune_table_roundtrip_and_tampering(tmp_path, sd, monkeypatch):
     table1 = cache.read_text()
     rows = [ln.split() for ln in table1.splitlines()]
     assert len(rows) >= 20 and all(len(r) == 3 and r[0].startswith("k5|") for r in rows)
+    capfd.readouterr()
     out2 = stamp()
     assert cache.read_text() == table1          # nothing was tuned again: every saved entry was read back and accepted
+    assert "does not fit" not in capfd.readouterr().err   # ... and none of its own entries failed validation
     assert torch.equal(out1, out2)
     # every entry rewritten to a halo tile with a 7-way split: invalid for the dense shapes and the LayerNorm folds, and for the
     # convs whose k-block count it does not divide into >= 9-block slices -- whatever survives validation must still be correct

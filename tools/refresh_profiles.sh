@@ -13,5 +13,8 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r02 -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-extras > /root/repo/gpurun_out/r02_prof.log 2>&1
 find /tmp/prof -name "*kernel_stats*" -exec cp {} /root/repo/gpurun_out/r02_kernel_stats.csv \;
+rm -rf /tmp/prof8
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof8 -o r02 -- python /root/repo/bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras > /root/repo/gpurun_out/r02_prof_b8.log 2>&1
+find /tmp/prof8 -name "*kernel_stats*" -exec cp {} /root/repo/gpurun_out/r02_kernel_stats_b8.csv \;
 cp /tmp/tc.txt /root/repo/gpurun_out/r02_tune_cache.txt
 cd /root/repo
