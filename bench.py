@@ -10,6 +10,10 @@ decoded u8 patches are gathered to rank 0 over RCCL inside the timed region.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--res R] [--ddim-steps S]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` without a launcher starts its N ranks itself (launch_ranks: rank r -> GPU r, a free rendezvous port on
+127.0.0.1, the synthetic weights generated ONCE and mapped by every rank, one shared tune table that rank 0 completes before the
+others read it).  `--batch 8 --gpus 8` is BASELINE configs[3]: 64 stamps sharded over 8 GPUs, one RCCL gather of the u8 patches.
+
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed inside this
 process) and `cpu_baseline` (the fp32 CPU oracle timed on a bounded sample, rank 0 / N=1 only).
 """
@@ -150,6 +154,104 @@ def extra_measurements(model512, sd):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------- multi-rank launch
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _shared_dir(need_bytes):
+    """A directory every rank of this node can map: /dev/shm when it has the room, the temp directory otherwise."""
+    import shutil
+    import tempfile
+    for d in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > need_bytes + (1 << 30):
+                return d
+        except OSError:
+            pass
+    return tempfile.gettempdir()
+
+
+def save_shared_weights(sd, prefix=None):
+    """Write {net: {key: tensor}} as ONE flat fp32 file + a JSON index, so that N ranks map the same pages instead of each
+    generating (12 s of host time for the 860 M UNet parameters) and holding its own 3.8 GB copy."""
+    import numpy as np
+    total = sum(t.numel() for net in sd.values() for t in net.values())
+    if prefix is None:
+        prefix = os.path.join(_shared_dir(total * 4), f"dtp_bench_weights_{os.getpid()}")
+    flat = np.lib.format.open_memmap(prefix + ".npy", mode="w+", dtype=np.float32, shape=(total,))
+    index, off = {}, 0
+    for net, tensors in sd.items():
+        index[net] = {}
+        for key, t in tensors.items():
+            n = t.numel()
+            flat[off:off + n] = t.detach().to(torch.float32).reshape(-1).numpy()
+            index[net][key] = [off, list(t.shape)]
+            off += n
+    flat.flush()
+    del flat
+    with open(prefix + ".json", "w") as f:
+        json.dump(index, f)
+    return prefix
+
+
+def load_shared_weights(prefix):
+    """The inverse: {net: {key: tensor}} of views into a private copy-on-write mapping of the shared file (never written)."""
+    import warnings
+    import numpy as np
+    index = json.load(open(prefix + ".json"))
+    flat = np.load(prefix + ".npy", mmap_mode="c")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        whole = torch.from_numpy(flat)
+    return {net: {key: whole[off:off + int(np.prod(shape, dtype=np.int64))].view(shape) for key, (off, shape) in tensors.items()}
+            for net, tensors in index.items()}
+
+
+def launch_ranks(a, argv):
+    """Start the N ranks of `python bench.py --gpus N` (what torch.distributed.run would do for us, minus the elastic agent): one
+    child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, all sharing the weights file and the tune
+    table.  Rank 0 prints the JSON line on our stdout; the exit code is the first non-zero child's."""
+    import subprocess
+    from diffusiontexturepainting_amd import weights as W
+    n = a.gpus
+    sd = dict(unet=W.synthetic_unet(), lora=W.synthetic_lora(), vae=W.synthetic_vae())
+    prefix = save_shared_weights(sd)
+    del sd
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), DTP_BENCH_WEIGHTS=prefix)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it across processes)
+    procs = []
+    try:
+        for r in range(n):
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv,
+                                          env=dict(env, RANK=str(r), LOCAL_RANK=str(r))))
+        rc, pending = 0, list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:  # one rank died: the others would wait in a collective forever
+                    rc = code
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.2)
+        return rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for ext in (".npy", ".json"):
+            try:
+                os.remove(prefix + ext)
+            except OSError:
+                pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,31 +270,53 @@ def main():
         print(json.dumps(cpu_config0()))
         return
 
+    # no launcher around us and more than one rank wanted (or DTP_BENCH_FORCE_DIST=1: a one-rank process group, which runs the RCCL
+    # code path -- init, barrier, all-reduce, the gather -- on a single-GPU box): start the ranks ourselves
+    if "RANK" not in os.environ and (a.gpus > 1 or os.environ.get("DTP_BENCH_FORCE_DIST")):
+        raise SystemExit(launch_ranks(a, sys.argv[1:]))
+
     from diffusiontexturepainting_amd import dist as D, synthetic, weights as W
     from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
 
     # DTP_BENCH_BACKEND=gloo + DTP_BENCH_SAME_DEVICE=1: every rank on GPU 0 -- exercises the N>1 control flow (rendezvous, shared
-    # tune cache, barriers, max-over-ranks timing, gather) on a 1-GPU box; the real runs use RCCL, one GPU per rank
-    rank, world, local = D.init_from_env(os.environ.get("DTP_BENCH_BACKEND", "nccl"))
+    # weights and tune table, staged build, barriers, max-over-ranks timing, gather) on a 1-GPU box; real runs use RCCL, one GPU per rank
+    backend = os.environ.get("DTP_BENCH_BACKEND", "nccl")
+    same_dev = bool(os.environ.get("DTP_BENCH_SAME_DEVICE"))
+    if same_dev:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = D.init_from_env(backend, force=bool(os.environ.get("DTP_BENCH_FORCE_DIST")))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
-    if os.environ.get("DTP_BENCH_SAME_DEVICE"):
-        local = 0
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}, "
+                         "or plainly as `python bench.py --gpus N` (it starts its ranks itself)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    distributed = torch.distributed.is_initialized()
 
-    sd = dict(unet=W.synthetic_unet(), lora=W.synthetic_lora(), vae=W.synthetic_vae())
-    model = MI355ConditionalInpainter(a.res, device=local, weights=sd, max_batch=max(a.batch, 8))
+    if os.environ.get("DTP_BENCH_WEIGHTS"):
+        sd = load_shared_weights(os.environ["DTP_BENCH_WEIGHTS"])  # generated once by launch_ranks, mapped by every rank
+    else:
+        sd = dict(unet=W.synthetic_unet(), lora=W.synthetic_lora(), vae=W.synthetic_vae())
     settings = dict(steps=a.ddim_steps, context_pad=150, tg_steps=a.ddim_steps, cfg_weight=2.0, tg_weight=1.0)  # Kit defaults
     canvas, brush, lat, eps = synthetic.make_stamp_batch(a.batch, a.res, seed=1000 + rank)
     cond, uncond = synthetic.make_conditioning(7)
+    n_total = a.batch * world
+
+    # Staged build: rank 0 creates its engine and runs one stamp (which builds and, where the shipped table has no entry, TUNES
+    # every launch program) before the other ranks start, so they find a complete tune table and never tune themselves.
+    if world > 1 and rank != 0:
+        D.barrier()
+    model = MI355ConditionalInpainter(a.res, device=local, weights=sd, max_batch=max(a.batch, 8))
     model.set_conditioning(cond, uncond, brush)  # replicated on every rank
     canvas, lat, eps = canvas.to(dev), lat.to(dev), eps.to(dev)
-    n_total = a.batch * world
+    model._stamp(canvas, settings, composite=True, latents=lat, vae_eps=eps, output_u8=True)
+    torch.cuda.synchronize()
+    if world > 1 and rank == 0:
+        D.barrier()
+    gatherer = D.PatchGatherer(n_total, (a.res, a.res, 3), torch.uint8, dev, rank, world) if distributed else None
 
     def one_step():
         out = model._stamp(canvas, settings, composite=True, latents=lat, vae_eps=eps, output_u8=True)
-        return D.gather_patches(out, n_total, rank, world)
+        return gatherer.gather(out) if gatherer else out
 
     for _ in range(a.warmup):
         one_step()
@@ -216,7 +340,7 @@ def main():
     if not a.no_profile and rank == 0:
         # one more pass of the same stamp with every launch bracketed by HIP events on its stream
         model.profile(True)
-        one_step() if world == 1 else model._stamp(canvas, settings, composite=True, latents=lat, vae_eps=eps, output_u8=True)
+        model._stamp(canvas, settings, composite=True, latents=lat, vae_eps=eps, output_u8=True)
         rows = model.profile_rows()
         if a.dump_launches:
             model.profile_dump(a.dump_launches)
@@ -254,7 +378,11 @@ def main():
     if rank == 0:
         lat_sorted = sorted(lat_ms)
         cfg_idx = {(1, 512, 20): 1, (8, 512, 20): 2, (1, 256, 8): 4}.get((a.batch, a.res, a.ddim_steps))
+        if (a.batch, a.res, a.ddim_steps, world) == (8, 512, 20, 8):
+            cfg_idx = 3  # batch 64 = 8 stamps on each of 8 GPUs, one gather of the decoded patches to rank 0
         cfg_name = f"BASELINE.json configs[{cfg_idx}]" if cfg_idx is not None else "not a BASELINE.json configuration"
+        if world > 1 and cfg_idx in (1, 2):
+            cfg_name += f" per GPU x {world} GPUs (weak scaling)"
         if cfg_idx == 4:
             cfg_name += " workload in fp16 (the fp8 variant is selected with DTP_FP8=1)"
         line = {
@@ -269,7 +397,9 @@ def main():
                                    "AutoencoderKL with seeded synthetic weights, conditioning cached",
                        "stamps_per_gpu_per_step": a.batch, "resolution": a.res, "ddim_steps": a.ddim_steps,
                        "unet_evals": info["unet_evals"], "graph_nodes": info["graph_nodes"],
-                       "gather": "rccl gather of u8 patches to rank 0" if world > 1 else "none (1 GPU)"},
+                       "gather": (f"{'rccl' if backend == 'nccl' else backend}: one gather of the u8 patches into a preallocated "
+                                  f"[{n_total}, {a.res}, {a.res}, 3] buffer on rank 0, inside the timed region") if distributed else "none (1 GPU)",
+                       "ranks_launched_by": "bench.py (launch_ranks)" if os.environ.get("DTP_BENCH_WEIGHTS") else ("torch.distributed.run" if distributed else "single process")},
             "p50_stamp_latency_ms": lat_sorted[len(lat_sorted) // 2], "p95_stamp_latency_ms": lat_sorted[int(len(lat_sorted) * 0.95)],
             "stage_ms": {"pre+vae_encode_x2": stage[0], "denoise_loop": stage[1], "vae_decode+post": stage[2]},
             "roofline": roof, "cpu_baseline": cpu, "extra_configs": extras,

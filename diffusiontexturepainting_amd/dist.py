@@ -12,19 +12,25 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
+def init_from_env(backend=None, force=False):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun, or bench.py's own launcher).
+    `force`: create the process group even for a single rank (the collectives then run through the backend -- RCCL on a
+    one-GPU box -- instead of being short-circuited)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        kw = {"timeout": datetime.timedelta(minutes=30)}  # ranks 1.. wait in a barrier while rank 0 builds (and may tune) first
+        if backend == "nccl":  # bind the communicator to this rank's GPU up front (no lazy guess from the first collective)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
@@ -36,27 +42,73 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+class PatchGatherer:
+    """The one data-path collective of the stamp path, with everything that is not the transfer itself hoisted out of it: rank
+    `dst` owns ONE preallocated [n_total, ...] result and the per-rank receive windows are contiguous VIEWS of it, so a gather is
+    a single collective straight into place -- no padding of ragged shards, no torch.cat afterwards.  Equal shards go through
+    `dist.gather` (RCCL implements it as one group of point-to-point transfers: 7 concurrent xGMI links into rank 0 on an 8-GPU
+    node); ragged shards use the same group built by hand (`batch_isend_irecv`), because a gather cannot carry different sizes.
+    gloo cannot move device memory: with that backend (CPU tests, the 2-ranks-on-one-GPU smoke run) the shard is staged through
+    a preallocated host buffer instead."""
+
+    def __init__(self, n_total, item_shape, dtype, device, rank, world, dst=0):
+        self.n_total, self.rank, self.world, self.dst = int(n_total), rank, world, dst
+        self.spans = [shard_range(self.n_total, r, world) for r in range(world)]
+        self.counts = [hi - lo for lo, hi in self.spans]
+        self.equal = len(set(self.counts)) == 1
+        self.device = torch.device(device)
+        self.backend = dist.get_backend() if dist.is_initialized() else None
+        self.stage_cpu = self.backend == "gloo" and self.device.type == "cuda"
+        work = torch.device("cpu") if self.stage_cpu else self.device
+        self.out = self.host = self.views = None
+        if rank == dst:
+            self.out = torch.empty((self.n_total,) + tuple(item_shape), dtype=dtype, device=work)
+            self.views = [self.out[lo:hi] for lo, hi in self.spans]
+        if self.stage_cpu:
+            self.host = torch.empty((self.counts[rank],) + tuple(item_shape), dtype=dtype, device="cpu")
+
+    def gather(self, local):
+        """local: this rank's [b_r, ...] patches.  Returns the assembled [n_total, ...] tensor on `dst` (the same preallocated
+        buffer every call: consume or copy it before the next gather), None elsewhere."""
+        if local.shape[0] != self.counts[self.rank]:
+            raise ValueError(f"rank {self.rank} holds {local.shape[0]} patches, its shard has {self.counts[self.rank]}")
+        if self.backend is None:
+            return local
+        local = local.contiguous()
+        if self.stage_cpu:
+            self.host.copy_(local)
+            local = self.host
+        if self.equal:
+            dist.gather(local, gather_list=self.views if self.rank == self.dst else None, dst=self.dst)
+        else:
+            ops = []
+            if self.rank == self.dst:
+                self.views[self.dst].copy_(local)
+                ops = [dist.P2POp(dist.irecv, self.views[r], r) for r in range(self.world) if r != self.dst and self.counts[r] > 0]
+            elif self.counts[self.rank] > 0:
+                ops = [dist.P2POp(dist.isend, local, self.dst)]
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+        if self.rank != self.dst:
+            return None
+        return self.out.to(self.device) if self.stage_cpu else self.out
+
+
+_gatherers = {}
+
+
 def gather_patches(local, n_total, rank, world, dst=0):
-    """Gather per-rank patch tensors [b_r, ...] to `dst` in stamp order -> [n_total, ...] on dst, None
-    elsewhere.  Shards may be ragged; every rank pads to the largest shard so the collective is a
-    single fixed-size gather."""
-    if world == 1:
+    """Gather per-rank patch tensors [b_r, ...] to `dst` in stamp order -> [n_total, ...] on dst, None elsewhere (shards may be
+    ragged).  A convenience wrapper that keeps one PatchGatherer per (shape, dtype, device, layout) alive: the result on `dst`
+    is that gatherer's preallocated buffer and is overwritten by the next call with the same key."""
+    if world == 1 and not dist.is_initialized():
         return local
-    sizes = [shard_range(n_total, r, world) for r in range(world)]
-    counts = [hi - lo for lo, hi in sizes]
-    mx = max(counts)
-    if local.shape[0] < mx:
-        pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        local = torch.cat([local, pad], dim=0)
-    local = local.contiguous()
-    dev = local.device
-    if dist.get_backend() == "gloo" and local.is_cuda:
-        local = local.cpu()  # gloo has no CUDA gather: stage through host memory (CPU tests and the single-GPU 2-rank smoke run)
-    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
-    dist.gather(local, gather_list=bufs, dst=dst)
-    if rank != dst:
-        return None
-    return torch.cat([b[:n] for b, n in zip(bufs, counts)], dim=0).to(dev)
+    key = (int(n_total), tuple(local.shape[1:]), local.dtype, str(local.device), rank, world, dst, dist.get_backend())
+    g = _gatherers.get(key)
+    if g is None:
+        g = _gatherers[key] = PatchGatherer(n_total, local.shape[1:], local.dtype, local.device, rank, world, dst)
+    return g.gather(local)
 
 
 def scatter_stamps(canvases, n_total, rank, world, src=0, device=None):

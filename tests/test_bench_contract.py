@@ -60,3 +60,30 @@ def test_config_labels():
     """Only the three BASELINE shapes may be labelled as BASELINE configurations (a --res 256 run used to be called configs[1])."""
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "{(1, 512, 20): 1, (8, 512, 20): 2, (1, 256, 8): 4}" in src and "not a BASELINE.json configuration" in src
+
+
+def test_shared_weight_file_round_trip(tmp_path):
+    """launch_ranks writes the synthetic weights once; every rank maps them: same keys, shapes and bits, and the mapping is private
+    (a write in one rank can never reach the file the others read)."""
+    import torch
+    bench = _bench()
+    g = torch.Generator().manual_seed(0)
+    sd = {"unet": {"a.weight": torch.randn(3, 5, 2, generator=g), "a.bias": torch.randn(3, generator=g)},
+          "vae": {"w": torch.randn(4, 4, generator=g)}, "lora": {}}
+    prefix = bench.save_shared_weights(sd, str(tmp_path / "w"))
+    back = bench.load_shared_weights(prefix)
+    assert set(back) == set(sd)
+    for net in sd:
+        assert list(back[net]) == list(sd[net])
+        for k in sd[net]:
+            assert back[net][k].shape == sd[net][k].shape and torch.equal(back[net][k], sd[net][k]) and back[net][k].is_contiguous()
+    back["vae"]["w"].zero_()
+    assert torch.equal(bench.load_shared_weights(prefix)["vae"]["w"], sd["vae"]["w"])
+
+
+def test_plain_multi_gpu_command_starts_its_own_ranks():
+    """`python bench.py --gpus N` must not need a launcher (the driver's 1-GPU command shape with a larger N): the dispatch happens
+    before anything touches a GPU, and a launcher-provided environment (RANK set) is respected."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if "RANK" not in os.environ and (a.gpus > 1 or os.environ.get("DTP_BENCH_FORCE_DIST")):' in src
+    assert src.index("launch_ranks(a, sys.argv[1:])") < src.index("D.init_from_env(")

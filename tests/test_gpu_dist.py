@@ -93,3 +93,42 @@ def test_two_ranks_on_one_gpu_match_a_single_process(tmp_path, monkeypatch):
         assert p.exitcode == 0
     assert res[1] is None and res[0].shape == (N_TOTAL, R, R, 3) and res[0].dtype == torch.uint8
     assert torch.equal(res[0], ref)
+
+
+def _run_bench(extra_env, *args, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_plain_bench_command_with_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: the script starts both ranks itself (shared weights file, shared tune table,
+    staged build, barriers, max-over-ranks timing, the gather into rank 0's preallocated buffer).  Both ranks share this box's
+    one GPU, so gloo carries the collectives; the 8-GPU run of the same command uses RCCL."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    line = _run_bench(dict(DTP_BENCH_BACKEND="gloo", DTP_BENCH_SAME_DEVICE="1"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                      "--res", "64", "--ddim-steps", "4", "--batch", "2", "--no-cpu-baseline", "--no-extras", "--no-profile")
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert abs(line["value"] - 4 * 1e3 / line["ms_per_step"]) / line["value"] < 1e-6  # whole job: 2 ranks x 2 stamps per step
+    assert line["config"]["gather"].startswith("gloo") and line["config"]["ranks_launched_by"].startswith("bench.py")
+
+
+def test_one_rank_process_group_runs_the_rccl_branches():
+    """DTP_BENCH_FORCE_DIST=1: a single rank with backend nccl (= RCCL) -- communicator creation on the GPU, barrier, the MAX
+    all-reduce of the timing and the gather of device-resident u8 patches all go through RCCL (a 1-GPU box cannot host more ranks:
+    RCCL wants one device per rank)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    line = _run_bench(dict(DTP_BENCH_FORCE_DIST="1"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--res", "64", "--ddim-steps", "4",
+                      "--batch", "2", "--no-cpu-baseline", "--no-extras", "--no-profile")
+    assert line["n_gpus"] == 1 and line["config"]["gather"].startswith("rccl") and line["value"] > 0
