@@ -311,6 +311,8 @@ int build_unet_prog(Ctx* c, int N, UNetProg& up) {
     for (int i = 1; i < 4; ++i) for (int j = 0; j < 3; ++j) all.push_back(&uw.up_xf[i][j]);
     for (XfW* x : all)
       for (ConvW* w : {&x->proj_in, &x->qkv, &x->out1, &x->ff1, &x->ff2_proj}) RC(ensure_w8(c, *w));
+    // the quantise kernels run on the null stream, the program on the caller's (non-blocking) stream: order them once, here
+    HIP_CHECK(hipDeviceSynchronize());
   }
   Builder b{c, &up.main};
   b.fp8 = c->fp8_linear;

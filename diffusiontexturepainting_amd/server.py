@@ -1,9 +1,13 @@
 """Serving core of the texture-painter backend: what trt_inference/run.py + handler.py do around the operator, plus the
 things a multi-client deployment needs:
 
-  * `StampHandler` -- the body of InpaintWebSocketHandler (handler.py:78-123) without the web framework: bytes in (the wire
-    format of server_io), bytes out through a `write_message(bytes)` callback.  A tornado handler is three lines on top of it
-    (`handler.on_message = lambda self, m: core.on_message(self.client_id, m, self.write_message)`).
+  * `StampServer.on_message` -- the body of InpaintWebSocketHandler (handler.py:78-123) without the web framework: bytes in (the
+    wire format of server_io), bytes out through a `write_message(bytes)` callback.  THREADING: replies are produced on the
+    replica's worker thread, and tornado's `WebSocketHandler.write_message` may only be called on the IOLoop thread (the reference
+    writes from the loop, handler.py:100-110).  Give the server a `post(fn, data)` hook that marshals onto the loop --
+    `StampServer(models, post=ioloop_post(tornado.ioloop.IOLoop.current()))` -- and a tornado handler is three lines on top:
+    `def on_message(self, m): core.on_message(self.client_id, m, self.write_message)`.  Without `post` the callback runs on the
+    worker thread as is (fine for thread-safe sinks: the tests' lists, a queue, a blocking socket owned by the caller).
   * `StampQueue` -- one per GPU replica.  Stamps of one stroke are serially dependent (the next canvas is rendered from the
     previous result, kit_app .../ui/brush.py:185-194), so ONE client never has two stamps in flight; DIFFERENT clients are
     independent.  The queue collects the stamps that are pending at the same time, groups those with equal inference
@@ -45,6 +49,14 @@ def decode_error_response(frame):
     return frame[5:5 + n].decode("utf-8", "replace")
 
 
+def ioloop_post(loop):
+    """`post` hook for StampServer / StampQueue: deliver every reply on a tornado IOLoop (`loop.add_callback` is the one IOLoop
+    method that is safe to call from another thread); works with any object offering add_callback(fn, *args, **kw)."""
+    def post(fn, data):
+        loop.add_callback(fn, data, binary=True)
+    return post
+
+
 def preview_mask(res):
     """handler.py:48-52: the top-left quadrant is 'already painted'."""
     m = torch.zeros(1, 1, res, res)
@@ -81,10 +93,13 @@ class StampQueue:
     """Work queue of ONE replica (one model on one GPU).  A worker thread drains it: brush changes run alone (they re-encode
     a slot), stamps pending at the same time are grouped by settings and batched."""
 
-    def __init__(self, model, max_batch=8, error_replies=False, gather_window_s=0.002, n_slots=16):
+    def __init__(self, model, max_batch=8, error_replies=False, gather_window_s=0.002, n_slots=16, post=None):
         self.model, self.max_batch, self.error_replies, self.window = model, int(max_batch), error_replies, gather_window_s
+        self.post = post               # post(reply_fn, data): how a reply leaves the worker thread (None: call reply_fn here)
         self.q = queue.Queue()
+        self.front = []                # requests taken off the queue while gathering a batch that did not belong to it: served first
         self.free_slots = list(range(n_slots))
+        self.brush_slots = set()       # slots whose CURRENT owner has set a brush (a recycled slot still holds the previous owner's)
         self.clients = {}              # client id -> slot
         self.batch_sizes = []          # size of every batched stamp call (observability / tests)
         self.lock = threading.Lock()
@@ -115,8 +130,17 @@ class StampQueue:
             return len(self.clients)
 
     def submit(self, job):
+        if self.stopping:  # nobody would ever take it off the queue
+            self._fail(job, RuntimeError("server is shutting down"))
+            return job
         self.q.put(job)
         return job
+
+    def _send(self, job, data):
+        if self.post is not None:
+            self.post(job.reply, data)
+        else:
+            job.reply(data)
 
     def close(self):
         """Stop the worker; requests that were still queued are failed (logged, error frame if enabled) instead of being left
@@ -124,11 +148,13 @@ class StampQueue:
         self.stopping = True
         self.q.put(None)
         self.worker.join(timeout=30)
+        leftovers, self.front = list(self.front), []
         while True:
             try:
-                job = self.q.get_nowait()
+                leftovers.append(self.q.get_nowait())
             except queue.Empty:
                 break
+        for job in leftovers:
             if job is not None:
                 self._fail(job, RuntimeError("server is shutting down"))
 
@@ -138,7 +164,7 @@ class StampQueue:
         logger.error("request of slot %d failed: %s", job.slot, job.error)  # what handler.py:88-89 does
         if self.error_replies:
             try:
-                job.reply(encode_error_response(job.error))
+                self._send(job, encode_error_response(job.error))
             except Exception:  # the socket may be gone
                 pass
         job.done.set()
@@ -147,15 +173,25 @@ class StampQueue:
         try:
             m = self.model
             m.set_brush(job.payload, slot=job.slot)                                   # handler.py:94
+            self.brush_slots.add(job.slot)
             mask = preview_mask(m.resolution()).to(m.device())                       # :95
             context = torch.cat([m.slot_image(job.slot).to(m.device()), mask], dim=1)  # :97
             result = m.generate(context, slots=[job.slot], **job.settings).cpu()     # :98
-            job.reply(sio.encode_generated_response(sio.RequestType.RETURN_PREVIEW, torch_to_np(result[0])))  # :100-101
+            self._send(job, sio.encode_generated_response(sio.RequestType.RETURN_PREVIEW, torch_to_np(result[0])))  # :100-101
             job.done.set()
         except Exception as e:
             self._fail(job, e)
 
     def _run_stamps(self, jobs):
+        # a recycled slot still holds its previous owner's brush in the engine: a client that stamps before sending its own
+        # brush gets "no brush set" (what the reference's fresh model would say), never another client's texture
+        ready = [j for j in jobs if j.slot in self.brush_slots]
+        for j in jobs:
+            if j.slot not in self.brush_slots:
+                self._fail(j, RuntimeError("no brush set for this client: send NEW_BRUSH_IMAGE first"))
+        jobs = ready
+        if not jobs:
+            return
         try:
             m = self.model
             canvas = torch.stack([j.payload for j in jobs]).to(m.device())            # handler.py:106, batched
@@ -169,62 +205,63 @@ class StampQueue:
             return
         for j, img in zip(jobs, result):
             try:
-                j.reply(sio.encode_generated_response(sio.RequestType.RETURN_STAMP, torch_to_np(img)))  # :109-110
+                self._send(j, sio.encode_generated_response(sio.RequestType.RETURN_STAMP, torch_to_np(img)))  # :109-110
             except Exception as e:
                 logger.error("reply failed: %s", e)
             j.done.set()
 
+    def _release(self, job):
+        with self.lock:
+            self.brush_slots.discard(job.slot)
+            self.free_slots.append(job.slot)
+        job.done.set()
+
+    def _next(self, timeout=None):
+        """Next request in ARRIVAL order: first what an earlier batch gather took off the queue and could not use."""
+        if self.front:
+            return self.front.pop(0)
+        return self.q.get(timeout=timeout) if timeout is not None else self.q.get()
+
     def _run(self):
         while True:
-            job = self.q.get()
+            job = self._next()
             if job is None:
                 return
             if self.stopping:  # close() was called while this request waited: answer it, do not run it
                 self._fail(job, RuntimeError("server is shutting down"))
                 continue
             if job.kind == "release":
-                with self.lock:
-                    self.free_slots.append(job.slot)
-                job.done.set()
+                self._release(job)
                 continue
             if job.kind == "brush":
                 self._run_brush(job)
                 continue
-            # gather what else is pending right now (plus a short window for stamps that are about to arrive)
+            # Gather the stamps that are pending right now (plus a short window for stamps that are about to arrive).  Gathering
+            # stops at the FIRST request that does not belong to the batch, of any kind: a stamp with other settings, a brush
+            # change or a slot release must not overtake -- or be overtaken by -- anything of its own client, so it is served
+            # next, in arrival order (it goes to `front`, never back to the tail of the queue).
             pending = [job]
-            held = []
             try:
                 while len(pending) < self.max_batch:
-                    nxt = self.q.get(timeout=self.window)
-                    if nxt is None:
-                        self.q.put(None)
-                        break
-                    if nxt.kind == "stamp" and _settings_key(nxt.settings) == _settings_key(job.settings):
+                    nxt = self._next(timeout=self.window)
+                    if nxt is not None and nxt.kind == "stamp" and _settings_key(nxt.settings) == _settings_key(job.settings):
                         pending.append(nxt)
                     else:
-                        held.append(nxt)   # a brush change, a slot release or other settings: next round, order among those preserved
-                        if nxt.kind != "stamp":
-                            break
+                        self.front.insert(0, nxt)  # including the shutdown sentinel: it is seen right after this batch
+                        break
             except queue.Empty:
                 pass
             self._run_stamps(pending)
-            for h in held:
-                if h.kind == "brush":
-                    self._run_brush(h)
-                elif h.kind == "release":
-                    with self.lock:
-                        self.free_slots.append(h.slot)
-                    h.done.set()
-                else:
-                    self.q.put(h)
 
 
 class StampServer:
     """Front of N replicas.  `on_message(client_id, message, write_message)` is the whole per-connection protocol
     (handler.py:78-123); `close_client` frees the client's slot."""
 
-    def __init__(self, models, max_batch=8, error_replies=False, gather_window_s=0.002):
-        self.queues = [StampQueue(m, max_batch=max_batch, error_replies=error_replies, gather_window_s=gather_window_s) for m in models]
+    def __init__(self, models, max_batch=8, error_replies=False, gather_window_s=0.002, post=None):
+        self.queues = [StampQueue(m, max_batch=max_batch, error_replies=error_replies, gather_window_s=gather_window_s, post=post)
+                       for m in models]
+        self.post = post
         self.route = {}  # client id -> queue index
         self.error_replies = error_replies
         self.lock = threading.Lock()
@@ -247,8 +284,10 @@ class StampServer:
             q.close()
 
     def on_message(self, client_id, message, write_message, wait=False):
-        """Decode one websocket message and enqueue the work; the reply is sent from the replica's worker thread through
-        `write_message`.  Returns the job (tests wait on job.done).  Decoding errors are handled like execution errors."""
+        """Decode one websocket message and enqueue the work; the reply leaves the replica's WORKER thread through `post`
+        (`post(write_message, bytes)`, e.g. ioloop_post(loop) for tornado) or, without one, by calling `write_message` there.
+        Returns the job (tests wait on job.done).  Decoding errors are handled like execution errors.  A client that reconnects
+        under a new id gets a fresh slot and has to send its brush again (the reference keeps ONE model-global brush)."""
         try:
             if not isinstance(message, (bytes, bytearray, memoryview)):
                 raise NotImplementedError("Json messages not handled")               # handler.py:125-129
@@ -268,7 +307,7 @@ class StampServer:
         except Exception as e:
             logger.error("Failed to decode incoming message: %s", e)                  # :88-89
             if self.error_replies:
-                write_message(encode_error_response(f"{type(e).__name__}: {e}"))
+                write_message(encode_error_response(f"{type(e).__name__}: {e}"))  # on the caller's (IOLoop) thread already
             return None
         q.submit(job)
         if wait:

@@ -176,3 +176,71 @@ def test_a_departed_clients_slot_is_recycled_only_after_its_pending_stamp():
     # a's queued stamp (cfg 3) ran with a's red brush, not with the blue one b brought: b got ANOTHER slot or came after it
     img = sio.decode_response(out["a"][-1])["image"].astype(np.float32)
     assert len(out["a"]) == 3 and img[..., 0].mean() > 10 * max(img[..., 2].mean(), 1e-3)
+
+
+def test_replies_leave_the_worker_thread_through_the_post_hook():
+    """tornado's write_message is not thread-safe: with a `post` hook every reply (results and error frames) is handed to the
+    loop instead of being called on the replica's worker thread."""
+    class Loop:  # what ioloop_post needs of tornado.ioloop.IOLoop: add_callback(fn, *args, **kw), callable from any thread
+        def __init__(self):
+            self.items, self.lock = [], threading.Lock()
+
+        def add_callback(self, fn, *args, **kw):
+            with self.lock:
+                self.items.append((threading.get_ident(), fn, args, kw))
+
+        def run_pending(self):
+            with self.lock:
+                items, self.items = self.items, []
+            for _, fn, args, kw in items:
+                fn(*args, **kw)
+
+    loop, sent, caller_threads = Loop(), [], []
+
+    def write_message(data, binary=False):
+        caller_threads.append(threading.get_ident())
+        sent.append((data, binary))
+
+    srv = S.StampServer([FakeModel(delay=0)], error_replies=True, post=S.ioloop_post(loop))
+    srv.on_message("c", _brush_msg((9, 9, 9)), write_message, wait=True)
+    srv.on_message("c", _stamp_msg(alpha=255, rgb=255), write_message, wait=True)  # poisoned: an error frame
+    assert sent == [] and len(loop.items) == 2 and all(t != threading.get_ident() for t, *_ in loop.items)  # produced on the worker ...
+    loop.run_pending()
+    assert [b for _, b in sent] == [True, True] and set(caller_threads) == {threading.get_ident()}        # ... written on "the loop"
+    assert sio.decode_response(sent[0][0])["type"] == sio.RequestType.RETURN_PREVIEW.value and sent[1][0][0] == S.RETURN_ERROR
+    srv.close()
+
+
+def test_requests_of_one_client_keep_their_order_across_a_batch_boundary():
+    """[stamp(cfg 10), stamp(cfg 3), brush] of one client: the second stamp has other settings, so it ends the first batch -- and
+    must still run BEFORE the brush change that arrived after it (it used to be re-queued behind it)."""
+    m = FakeModel(delay=0.05)
+    srv = S.StampServer([m], max_batch=8, gather_window_s=0.05)
+    out = []
+    srv.on_message("c", _brush_msg((200, 0, 0)), out.append, wait=True)
+    j1 = srv.on_message("c", _stamp_msg(cfg=10.0), out.append)
+    j2 = srv.on_message("c", _stamp_msg(cfg=5.0), out.append)
+    j3 = srv.on_message("c", _brush_msg((0, 0, 200)), out.append)
+    assert j1.done.wait(5) and j2.done.wait(5) and j3.done.wait(5)
+    kinds = [sio.decode_response(o)["type"] for o in out]
+    assert kinds == [sio.RequestType.RETURN_PREVIEW.value, sio.RequestType.RETURN_STAMP.value, sio.RequestType.RETURN_STAMP.value,
+                     sio.RequestType.RETURN_PREVIEW.value]
+    img = sio.decode_response(out[2])["image"].astype(np.float32)  # the cfg-5 stamp: painted with the RED brush
+    assert img[..., 0].mean() > 50 and img[..., 2].mean() < 5
+    srv.close()
+    late = srv.on_message("c", _stamp_msg(), out.append)           # after close(): failed at once, nobody waits for ever
+    assert late.done.wait(1) and "shutting down" in late.error
+
+
+def test_a_recycled_slot_does_not_leak_the_previous_clients_brush():
+    m = FakeModel(delay=0)
+    srv = S.StampServer([m], error_replies=True)
+    a, b = [], []
+    srv.on_message("a", _brush_msg((250, 0, 0)), a.append, wait=True)
+    srv.close_client("a")
+    j = srv.on_message("b", _stamp_msg(), b.append, wait=True)      # b inherits a's slot but has not sent a brush yet
+    assert j.error and "no brush set" in j.error and b[0][0] == S.RETURN_ERROR and not m.calls[1:]
+    srv.on_message("b", _brush_msg((0, 250, 0)), b.append, wait=True)
+    ok = srv.on_message("b", _stamp_msg(cfg=10.0), b.append, wait=True)
+    assert ok.error is None and sio.decode_response(b[-1])["image"][..., 1].mean() > 200
+    srv.close()
