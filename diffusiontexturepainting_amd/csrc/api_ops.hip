@@ -163,6 +163,17 @@ int dtp_op_groupnorm(const void* x, int ldx, void* y, int ldy, const float* gamm
                               (hipStream_t)s);
 }
 
+int dtp_op_reduce_groupnorm(const float* part, int splits, const float* bias, const void* resid, void* conv_out, void* y, const float* gamma,
+                            const float* beta, int B, int HW, int C, int groups, float eps, int silu, dtp_stream s) {
+  std::lock_guard<std::mutex> lk(g_ops_mu);
+  int rc = ops_init();
+  if (rc) return rc;
+  rc = ops_ws(dtp_groupnorm_ws_bytes(B, HW, C, groups));
+  if (rc) return rc;
+  return dtp_launch_reduce_groupnorm(part, splits, (long long)B * HW * C, C, bias, (const f16*)resid, C, (f16*)conv_out, C, (f16*)y, C, gamma, beta, B, HW, C,
+                                     groups, eps, silu, g_ops.ws, (hipStream_t)s);
+}
+
 int dtp_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int rows, int C,
                      float eps, dtp_stream s) {
   return dtp_launch_layernorm((const f16*)x, ldx, (f16*)y, ldy, gamma, beta, rows, C, eps, (hipStream_t)s);

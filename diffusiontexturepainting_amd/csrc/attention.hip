@@ -29,6 +29,7 @@
 // Built with -ffast-math: masking uses a finite sentinel, never inf/nan.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
     // ---- S^T = K Q^T  (two 32-key blocks)
     f32x16 sacc[2];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : sacc[kb], 0, 0, 0);
       }
     }
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
     // ---- online softmax over this lane's 32 keys (+ the other half-wave's 32)
     if (kv0 + 64 > p.Skv) {  // tail tile: mask keys beyond Skv
 #pragma unroll
@@ -271,6 +274,7 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
       }
       if (!ONES) l_run += lsum + __shfl_xor(lsum, 32);
     }
+    if (p.prio & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
 #pragma unroll
@@ -281,6 +285,7 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s], oacc[db], 0, 0, 0);
         }
     }
+    if (p.prio & 2) __builtin_amdgcn_s_setprio(0);
     if constexpr (NBUF == 2) {
       // the other buffer was last read during the previous tile, which every wave left before the previous barrier
       if (more) stage(buf ^ 1);
@@ -309,7 +314,10 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
 
 }  // namespace
 
-int dtp_launch_attention(const AttnParams& p, hipStream_t s) {
+int dtp_launch_attention(const AttnParams& pin, hipStream_t s) {
+  AttnParams p = pin;
+  static const int prio_env = [] { const char* e = getenv("DTP_ATTN_PRIO"); return e ? atoi(e) : 0; }();
+  p.prio = prio_env;
   if ((p.D & 7) || (p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.ldo & 3) || p.Skv < 1 || p.Sq < 1) {
     dtp_set_error("attention: D=%d ldq=%d ldk=%d ldv=%d ldo=%d unsupported", p.D, p.ldq, p.ldk, p.ldv, p.ldo);
     return DTP_ERR_ARG;

@@ -145,11 +145,12 @@ int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* ga
                          int B, int HW, int C, int groups, float eps, int silu, hipStream_t s);
 size_t dtp_groupnorm_ws_bytes(int B, int HW, int C, int groups);
 // split-K reduce (+ bias, + residual) of a conv output fused with the GroupNorm (+SiLU) that consumes it: writes the fp16 conv
-// output c_out AND the normalised tensor y in one launch (HW <= 256)
+// output c_out AND the normalised tensor y -- in one launch where dtp_reduce_groupnorm_supported() (HW <= 256), otherwise the
+// reduce rides in the statistics pass of the two-launch GroupNorm (needs stats_ws, dtp_groupnorm_ws_bytes)
 bool dtp_reduce_groupnorm_supported(int HW, int C, int groups);
 int dtp_launch_reduce_groupnorm(const float* part, int splits, long long slab, int ldp, const float* bias, const f16* R, int ldr,
                                 f16* c_out, int ldc, f16* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
-                                int groups, float eps, int silu, hipStream_t s);
+                                int groups, float eps, int silu, float* stats_ws, hipStream_t s);
 int dtp_launch_layernorm(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, int rows, int C,
                          float eps, hipStream_t s);
 int dtp_launch_softmax_rows(const f16* x, int ldx, f16* y, int ldy, int rows, int cols, float scale, hipStream_t s);
@@ -162,6 +163,7 @@ struct AttnParams {
   int B, H, Sq, Skv, D;         // head h reads columns [h*D, (h+1)*D)
   long long qbs, kbs, vbs, obs; // batch strides (elements)
   float scale;
+  int prio;  // experiment ($DTP_ATTN_PRIO): raise the wave priority around the MFMA clusters
 };
 int dtp_launch_attention(const AttnParams& p, hipStream_t s);
 // attention_fp8.hip: the same contraction on the fp8 (e4m3) MX MFMA; q_scale / v_scale = per-tensor scales (powers of two)
@@ -170,6 +172,16 @@ int dtp_launch_attention_fp8(const AttnParams& p, float q_scale, float v_scale, 
 // ---------------------------------------------------------------- elementwise / layout (elementwise.hip)
 int dtp_launch_concat_channels(const f16* a, int lda, int Ca, const f16* b, int ldb, int Cb, f16* y, int ldy, long long rows,
                                hipStream_t s);
+// several strided row copies in one launch (rows of row_bytes bytes; everything 16-byte aligned)
+#define DTP_COPY_SEGS 8
+struct CopySegs {
+  int n;
+  const char* src[DTP_COPY_SEGS];
+  char* dst[DTP_COPY_SEGS];
+  long long rows[DTP_COPY_SEGS], row_bytes[DTP_COPY_SEGS], src_stride[DTP_COPY_SEGS], dst_stride[DTP_COPY_SEGS];
+  long long chunks[DTP_COPY_SEGS], total;  // filled by the launcher
+};
+int dtp_launch_copy_rows(CopySegs segs, hipStream_t s);
 int dtp_launch_f32_to_f16(const float* x, f16* y, long long n, hipStream_t s);
 int dtp_launch_nchw_f32_to_nhwc_f16(const float* x, f16* y, int B, int C, int HW, int Cpad, hipStream_t s);
 int dtp_launch_nhwc_f16_to_nchw_f32(const f16* x, int ldx, float* y, int B, int C, int HW, hipStream_t s);

@@ -203,6 +203,37 @@ __global__ __launch_bounds__(256) void matmul_f32_kernel(const float* __restrict
 
 #define LAUNCH_RET() return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP
 
+namespace {
+// up to DTP_COPY_SEGS strided row copies in ONE launch (16-byte chunks): the duplication of the uncond / cond prefix tensors
+__global__ __launch_bounds__(256) void copy_rows_kernel(const CopySegs segs) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < segs.total; i += stride) {
+    long long j = i;
+    int k = 0;
+    while (k + 1 < segs.n && j >= segs.chunks[k]) { j -= segs.chunks[k]; ++k; }
+    const long long cpr = segs.row_bytes[k] >> 4;  // chunks per row
+    const long long r = j / cpr, c = j - r * cpr;
+    *(f32x4*)(segs.dst[k] + r * segs.dst_stride[k] + c * 16) = *(const f32x4*)(segs.src[k] + r * segs.src_stride[k] + c * 16);
+  }
+}
+}  // namespace
+
+int dtp_launch_copy_rows(CopySegs segs, hipStream_t s) {
+  segs.total = 0;
+  for (int k = 0; k < segs.n; ++k) {
+    if ((segs.row_bytes[k] & 15) || (segs.src_stride[k] & 15) || (segs.dst_stride[k] & 15) || ((uintptr_t)segs.src[k] & 15) || ((uintptr_t)segs.dst[k] & 15)) {
+      dtp_set_error("copy_rows: segment %d is not 16-byte aligned", k);
+      return DTP_ERR_ARG;
+    }
+    segs.chunks[k] = segs.rows[k] * (segs.row_bytes[k] >> 4);
+    segs.total += segs.chunks[k];
+  }
+  if (segs.total == 0) return DTP_OK;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(segs.total)), dim3(256), 0, s, segs);
+  LAUNCH_RET();
+}
+
 int dtp_launch_concat_channels(const f16* a, int lda, int Ca, const f16* b, int ldb, int Cb, f16* y, int ldy, long long rows,
                                hipStream_t s) {
   if ((Ca | Cb | lda | ldb | ldy) & 7) { dtp_set_error("concat: channel counts / strides must be multiples of 8"); return DTP_ERR_ARG; }

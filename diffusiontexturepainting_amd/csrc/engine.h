@@ -50,7 +50,7 @@ struct Ctx;
 // A launch program: a flat list of closures bound to statically planned buffers.
 using Op = std::function<int(hipStream_t, int /*step*/)>;
 // profiling classes (dtp_profile_rows): 0-11 = gemm_kernel<BM,BN,NS> variants (id = shape + 4*(NS-2)), then the rest
-enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_BIG0 = 21, PK_WIDE0 = 25, PK_FP8 = 27, PK_KH2 = 28, PK_COUNT = 36 };
+enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_BIG0 = 21, PK_WIDE0 = 25, PK_FP8 = 27, PK_KH2 = 28, PK_LW = 36, PK_COUNT = 44 };
 struct ProfRec {
   int kind;
   double flops, bytes;
@@ -210,7 +210,7 @@ struct Ctx {
   ImgEncW ienc;
 
   // programs keyed by batch
-  std::map<int, UNetProg> unet_progs;
+  std::map<int, UNetProg> unet_progs;  // key = N * 64 + dupB (dupB = samples filled by duplication, 0 = none)
   std::map<int, VaeEncProg> enc_progs;
   std::map<int, VaeDecProg> dec_progs;
 
@@ -240,6 +240,7 @@ struct Ctx {
   IencBufs ienc_bufs;
   int* finite_flag = nullptr;     // device: set to 1 by the post-loop finiteness check ("check_finite" option)
   bool check_finite = false;
+  bool dedupe_prefix = true;      // uncond and cond branches share the UNet prefix up to the first cross-attention ($DTP_NO_DEDUPE=1: off, A/B)
   bool fuse_reduce_gn = true;     // fold a split-K conv's reduce into the GroupNorm that consumes it ($DTP_NO_FUSE_REDUCE_GN=1: off, A/B)
   bool fp8_linear = false;        // UNet transformer Linears / 1x1 convs on the fp8 MX MFMA (configs[4]); fixed once a UNet program exists
   bool fp8_attention = false;     // UNet self-attention on the fp8 MX MFMA (BASELINE configs[4]); fixed once a UNet program exists
@@ -286,6 +287,8 @@ int load_plain_f16(Ctx* c, const std::string& name, f16** out);  // unpadded fp1
 struct RowStats {
   float* buf = nullptr;  // [parts][M][2]
   int parts = 0, M = 0;
+  // the producer covers only rows [row_off, row_off + its M) of a rows_total-row table (de-duplicated prefix, unet.hip)
+  int rows_total = 0, row_off = 0;
 };
 
 // ---- builder helpers (engine.hip): every function appends ops to `prog` and returns planned buffers
@@ -314,7 +317,7 @@ struct Builder {
   int resnet(const T& x, const ResW& w, float eps, bool temb, T& y, const T* dst = nullptr);
 };
 
-int build_unet_prog(Ctx* c, int N, UNetProg& up);
+int build_unet_prog(Ctx* c, int N, int dupB, UNetProg& up);
 int build_vae_enc_prog(Ctx* c, int B, VaeEncProg& p);
 int build_vae_dec_prog(Ctx* c, int B, VaeDecProg& p);
 int load_unet_weights(Ctx* c);

@@ -347,7 +347,7 @@ int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
   const LastGemm lg = prog->last_gemm;
   const int keep = GF_BIAS | GF_RESID | GF_CONV3 | GF_UPS2 | GF_MFAST;
   if (cc->fuse_reduce_gn && lg.valid && lg.p.splits > 1 && (f16*)lg.p.C == x.p && lg.p.ldc == x.ld && lg.p.M == (int)x.rows() && lg.p.N == x.C &&
-      !(lg.p.flags & ~keep) && lg.p.batch <= 1 && dtp_reduce_groupnorm_supported(x.H * x.W, x.C, 32)) {
+      !(lg.p.flags & ~keep) && lg.p.batch <= 1 && (x.C & 7) == 0) {
     GemmParams gp = lg.p;
     gp.flags |= GF_NOREDUCE;
     prog->ops[lg.op_index] = Op();  // rebuilt below through the profiling wrapper
@@ -355,10 +355,14 @@ int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
     prog_push(cc, prog, lg.kind, lg.flops, lg.bytes, make_gemm_op(cc, gp, lg.tile, lg.bias_step_off), lg.label + " (reduce in gn)");
     const int bso = lg.bias_step_off;
     const bool has_bias = (gp.flags & GF_BIAS) != 0;
+    // small maps: one launch does it all; large maps: the reduce rides in the statistics pass, whose partial sums live behind the slabs
+    const size_t slab_bytes = (dtp_gemm_workspace_bytes(gp) + 255) & ~(size_t)255;
+    cc->ws_need = std::max(cc->ws_need, slab_bytes + dtp_groupnorm_ws_bytes(x.B, x.H * x.W, x.C, 32));
     push(PK_GN, 0.0, 4.0 * (double)xx.rows() * xx.C, [=](hipStream_t s, int step) {
       const float* bias = !has_bias ? nullptr : (bso >= 0 ? cc->temb_table + (size_t)step * cc->unet.temb_total + bso : gp.bias);
       return dtp_launch_reduce_groupnorm(cc->ws, gp.splits, (long long)gp.M * gp.N, gp.N, bias, (gp.flags & GF_RESID) ? gp.R : nullptr, gp.ldr,
-                                         xx.p, xx.ld, yy.p, yy.ld, nn.g, nn.b, xx.B, xx.H * xx.W, xx.C, 32, eps, silu ? 1 : 0, s);
+                                         xx.p, xx.ld, yy.p, yy.ld, nn.g, nn.b, xx.B, xx.H * xx.W, xx.C, 32, eps, silu ? 1 : 0,
+                                         (float*)((char*)cc->ws + slab_bytes), s);
     }, "reduce+gn B=" + std::to_string(x.B) + " HW=" + std::to_string(x.H * x.W) + " C=" + std::to_string(x.C) + " splits=" + std::to_string(gp.splits));
     return DTP_OK;
   }
@@ -386,7 +390,7 @@ static void tune_read_file(Ctx* c, const char* path) {
   char key[256];
   int tile, splits;
   while (fscanf(f, "%255s %d %d", key, &tile, &splits) == 3)
-    if (tile >= 0 && tile < 40 && splits >= 1 && splits <= 64) c->tuned[key] = std::make_pair(tile, splits);  // shape-level checks: tune_entry_valid()
+    if (tile >= 0 && tile < 48 && splits >= 1 && splits <= 64) c->tuned[key] = std::make_pair(tile, splits);  // shape-level checks: tune_entry_valid()
   fclose(f);
 }
 
@@ -438,8 +442,8 @@ void tune_cache_save(Ctx* c) {
 // with every tile variant x split-K factor on the real buffers and the fastest pair is kept.
 static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   char key[200];
-  // "k5|": bump when tile ids or pipelines change, so that a persisted table written by an older build is ignored
-  int kl = snprintf(key, sizeof(key), "k5|%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
+  // "k6|": bump when tile ids or pipelines change, so that a persisted table written by an older build is ignored
+  int kl = snprintf(key, sizeof(key), "k6|%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
                     p.stride, p.lda, p.ldc, p.ldw, p.st_parts, p.Cin2, p.lda2);
   if (p.batch > 1) kl += snprintf(key + kl, sizeof(key) - kl, ",b%d", p.batch);
   if (p.W8) snprintf(key + kl, sizeof(key) - kl, ",f8");
@@ -493,7 +497,7 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     };
     struct Cand { float ms; int tile, sp; };
     std::vector<Cand> cands;
-    for (int tile = 0; tile < 40; ++tile) {  // 4 tile shapes x 3 pipeline depths, the 256-row / 256-column tiles, the 8-wave wide tiles, fp8, the 8-wave twins of the small shapes
+    for (int tile = 0; tile < 48; ++tile) {  // 4 tile shapes x 3 pipeline depths, the 256-row / 256-column tiles, the 8-wave wide tiles, fp8, the 8-wave twins of the small shapes, their loader-wave variants
       int bm = 0, bn = 0, ns = 0;
       if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) continue;
       // fp8 tiles need the e4m3 weight copy.  An fp8 problem keeps the choice of an fp16 tile while it is small (the register-
@@ -625,7 +629,7 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
            p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? (f8tile ? " geglu fp8" : " geglu") : (f8tile ? " fp8" : ""), p.stride == 2 ? " s2" : "",
            p.batch > 1 ? (" x" + std::to_string(p.batch)).c_str() : "");
-  const int kind = tile >= 32 ? PK_KH2 + tile - 32 : tile >= 24 ? PK_FP8 : tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
+  const int kind = tile >= 40 ? PK_LW + tile - 40 : tile >= 32 ? PK_KH2 + tile - 32 : tile >= 24 ? PK_FP8 : tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
   const double flops = 2.0 * nb * p.M * (double)p.N * k_alg;
   prog_push(c, prog, kind, flops, bytes, make_gemm_op(c, p, tile, bias_step_off), lab);
   if (p.splits > 1) {  // a GroupNorm pushed next may take over the reduce (Builder::gn)
@@ -696,7 +700,10 @@ int Builder::linear(const T& x, const ConvW& w, const T* resid, int flags, T& y,
     if (use && use->buf && use->parts > 0 && use->M == p.M) { p.st_in = use->buf; p.st_parts = use->parts; }
   }
   if (resid) { p.flags |= GF_RESID; p.R = resid->p; p.ldr = resid->ld; }
-  if (emit && emit->buf) { p.flags |= GF_ROWSTATS; p.st_out = emit->buf; }
+  if (emit && emit->buf) {
+    p.flags |= GF_ROWSTATS; p.st_out = emit->buf;
+    if (emit->rows_total > 0) { p.st_out = emit->buf + (size_t)emit->row_off * 2; p.st_rows = emit->rows_total; }
+  }
   if (fp8 && w.w8) {
     GemmParams q = p;
     q.W8 = w.w8; q.ldw8 = w.ldw8; q.w_scale = w.w8_scale; q.a_scale = 1.0f; q.splits = 1;
@@ -768,6 +775,7 @@ int dtp_create(int device, int resolution, int max_batch, dtp_ctx** out) {
   for (int i = 0; i < 4; ++i) HIP_CHECK(hipEventCreate(&c->ev[i]));
   tune_cache_load(c);
   if (const char* e = getenv("DTP_NO_FUSE_REDUCE_GN")) c->fuse_reduce_gn = !(e[0] && e[0] != '0');
+  if (const char* e = getenv("DTP_NO_DEDUPE")) c->dedupe_prefix = !(e[0] && e[0] != '0');
   *out = (dtp_ctx*)c;
   return DTP_OK;
 }

@@ -37,8 +37,15 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // accumulators are summed through LDS after the loop.  One 4-wave workgroup per CU fills its LDS at ~26 B/clk -- a wave issues an
 // LDS-DMA piece every ~130 cycles -- so the mid-size contractions of a batch-1 stamp (grids of <= 256 workgroups) are bound by
 // that; a second wave per SIMD doubles the issue rate without a second workgroup's fp32 split-K slab.
-template <int BM, int BN, int NS, int KH = 1>
-__global__ __launch_bounds__(256 * KH) void gemm_kernel(const GemmParams pin) {
+// LW > 0: LOADER WAVES.  The 4 * KH consumer waves only read fragments and multiply; LW extra waves of the workgroup do nothing but
+// issue the LDS-DMA of the k-blocks ahead (and carry the im2col / two-operand bookkeeping that goes with it).  Inside a consumer
+// wave a DMA piece costs 60-180 cycles of issue next to its ds_reads and MFMAs -- for the small tiles of a batch-1 stamp (4-16
+// MFMAs per wave and k-block) that, not the matrix pipe, was the k-block time; a dedicated wave issues a piece
+// every ~25-40 cycles and stalls nobody.  Same LDS image, same ring, same counted-vmcnt protocol: the loader waits for ITS
+// k-block t, everyone meets at the barrier, the loader then refills the slot the consumers have just left.  Loader waves end
+// after the last k-block (s_barrier only counts the waves that are still alive), the epilogue belongs to the consumers.
+template <int BM, int BN, int NS, int KH = 1, int LW = 0>
+__global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmParams pin) {
   GemmParams p = pin;
   const int st_rows = p.st_rows > 0 ? p.st_rows : p.M;
   const int st_m0 = (p.batch > 1) ? (int)blockIdx.y * p.M : 0;
@@ -51,10 +58,13 @@ __global__ __launch_bounds__(256 * KH) void gemm_kernel(const GemmParams pin) {
     if (p.lns) p.lns += bz * p.lns_bs;
   }
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA blocks per wave along M / N
-  constexpr int NT = 256 * KH, RPR = 32 * KH;  // threads; LDS rows filled by one DMA round of all waves
+  constexpr int NT = 256 * KH;                 // consumer threads (fragment reads, MFMAs, epilogue)
+  constexpr int RPR = LW ? 8 * LW : 32 * KH;   // LDS rows filled by one DMA round of all DMA-issuing waves
   constexpr int KS = 4 / KH;                   // k-steps of a k-block multiplied by one wave
-  constexpr int AR = BM / RPR, WR = BN / RPR;  // DMA wave-instructions per wave per k-block
+  constexpr int AR = BM / RPR, WR = BN / RPR;  // DMA wave-instructions per issuing wave per k-block
   static_assert(BM % RPR == 0 && BN % RPR == 0 && (KH == 1 || KH == 2), "tile / wave grid mismatch");
+  static_assert(LW == 0 || (NS >= 3 && (NS - 2) * (AR + WR) <= 63), "loader waves: ring depth >= 3, counted vmcnt must fit its 6 bits");
+  static_assert(LW % 2 == 0, "the per-wave swizzle key (lrow >> 1) & 7 is the tile row's only while 8 * LW is a multiple of 16");
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int SLD = BN + 8;                // staging-tile row stride (f16)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,6 +72,8 @@ __global__ __launch_bounds__(256 * KH) void gemm_kernel(const GemmParams pin) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wq = wave & 3, kh = wave >> 2;  // quadrant of the tile / half of the k-block this wave multiplies
+  const bool loader = LW > 0 && wave >= 4 * KH;
+  const int dwave = LW > 0 ? wave - 4 * KH : wave;  // index among the DMA-issuing waves (only used by those)
 
   // ---- XCD-aware tile assignment (bijective remap; block b runs on XCD b % 8)
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(256 * KH) void gemm_kernel(const GemmParams pin) {
 
   // ---- DMA source state.  Row r = i*RPR + wave*8 + (lane>>3); LDS slot = lane&7 holds source
   // chunk slot ^ ((r>>1)&7).
-  const int lrow = wave * 8 + (lane >> 3);
+  const int lrow = dwave * 8 + (lane >> 3);
   const int kc = (((lane & 7) ^ ((lrow >> 1) & 7)) << 3);  // element offset inside the k-block
   const bool conv = (p.flags & GF_CONV3) != 0;
   const int ups = (p.flags & GF_UPS2) ? 1 : 0;
@@ -166,8 +178,8 @@ __global__ __launch_bounds__(256 * KH) void gemm_kernel(const GemmParams pin) {
   };
   auto piece = [&](int stage, int q) {
     char* As = smem + stage * STAGE;
-    if (q < AR) glds16(a_row[q] ? a_row[q] + a_off : p.zero, As + (q * RPR + wave * 8) * 128);
-    else glds16((BN <= 128 || w_row[q - AR]) ? w_row[q - AR] + w_off : p.zero, As + BM * 128 + ((q - AR) * RPR + wave * 8) * 128);
+    if (q < AR) glds16(a_row[q] ? a_row[q] + a_off : p.zero, As + (q * RPR + dwave * 8) * 128);
+    else glds16((BN <= 128 || w_row[q - AR]) ? w_row[q - AR] + w_off : p.zero, As + BM * 128 + ((q - AR) * RPR + dwave * 8) * 128);
   };
   auto issue = [&](int stage, int kb) {
     prep(kb);
@@ -187,9 +199,29 @@ __global__ __launch_bounds__(256 * KH) void gemm_kernel(const GemmParams pin) {
   const int frow = lane & 31, fhalf = lane >> 5;
 
   constexpr int LOADS = AR + WR;  // DMA instructions per wave per stage
+  if constexpr (LW > 0) {
+    if (loader) {  // ---- the whole life of a loader wave
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nk) issue(s, kb0 + s);
+      for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s, kb0 + s);
+      int nxt = NS - 1;
+      for (int t = 0; t < nk; ++t) {
+        // k-block t has landed once at most `ahead` younger stages of this wave are still outstanding
+        const int ahead = min(NS - 2, nk - 1 - t);
+        if (ahead <= 0) wait_vmcnt<0>();
+        else if (ahead == 1) wait_vmcnt<LOADS>();
+        else wait_vmcnt<(NS > 3 ? 2 * LOADS : LOADS)>();
+        __builtin_amdgcn_s_barrier();  // k-block t is complete in LDS; the consumers have left k-block t-1: its slot is free
+        if (t + NS - 1 < nk) issue(nxt, kb0 + t + NS - 1);
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+      }
+      return;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < nk) issue(s, kb0 + s);
+  }
   // ---- fused LayerNorm (GF_LNFOLD): while the first DMA stages are in flight, compute mean / rstd of this tile's
   // BM rows over the full K = C columns (16 lanes per row, 16-byte loads; the rows are L2/Infinity-Cache resident:
   // they were written by the previous kernel).  Applied in the epilogue, so the normalised tensor never exists.
@@ -310,9 +342,17 @@ __global__ __launch_bounds__(256 * KH) void gemm_kernel(const GemmParams pin) {
       nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
   };
-  const int t_steady = max(0, nk - (NS - 1));
-  run(std::true_type{}, 0, t_steady);
-  run(std::false_type{}, t_steady, nk);
+  if constexpr (LW > 0) {
+    for (int t = 0; t < nk; ++t) {
+      __builtin_amdgcn_s_barrier();
+      kblock(std::false_type{});
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+    }
+  } else {
+    const int t_steady = max(0, nk - (NS - 1));
+    run(std::true_type{}, 0, t_steady);
+    run(std::false_type{}, t_steady, nk);
+  }
 
   // ---------------------------------------------------------------- epilogue
   if constexpr (KH == 2) {  // sum the two k-halves: waves 4-7 hand their accumulators to waves 0-3 through the (now free) stages
@@ -585,13 +625,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
   if (lane == 0) { p.st_out[(size_t)m * 2] = s1; p.st_out[(size_t)m * 2 + 1] = s2; }
 }
 
-template <int BM, int BN, int NS, int KH = 1>
+template <int BM, int BN, int NS, int KH = 1, int LW = 0>
 int launch_tile(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   constexpr int lds = NS * (BM + BN) * 128 + BM * 8;  // + per-row LayerNorm statistics
   static_assert(lds - BM * 8 >= BM * (BN + 8) * 2, "staging tile must fit in the pipeline buffers");
   static_assert(lds <= 160 * 1024, "LDS budget");
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS, KH>), dim3(tiles, p.batch > 1 ? p.batch : 1, p.splits), dim3(256 * KH), lds, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS, KH, LW>), dim3(tiles, p.batch > 1 ? p.batch : 1, p.splits), dim3(256 * KH + 64 * LW), lds, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
@@ -605,6 +645,15 @@ int launch_tile(const GemmParams& p, hipStream_t s) {
 #define FOR_ALL_KH2(X) \
   X(128, 128, 2) X(128, 128, 3) X(128, 64, 2) X(128, 64, 3) X(64, 64, 2) X(64, 64, 3) X(64, 128, 2) X(64, 128, 3)
 
+// loader-wave variants (LW > 0), tile ids 40..47: shape (id & 3) of {128x128, 128x64, 64x64, 64x128} at depth 3;
+// 40..43: 4 loader waves (8 waves in all), 44..47: 8 loader waves (12 in all).
+// One wave issues an LDS-DMA piece every ~170 cycles whatever its queue depth (tools/micro/ldsdma_rate.hip: 6 B/clk per wave,
+// 22 / 38 / 50 B/clk per CU from 4 / 8 / 16 issuing waves, L2-resident source), so the fill rate of a lone workgroup is set by HOW
+// MANY waves issue; 2 loaders were never ahead of the 4-wave kernel (tools/diag_lw.py) and are not built.
+#define FOR_ALL_LW(X) \
+  X(128, 128, 3, 4) X(128, 64, 3, 4) X(64, 64, 3, 4) X(64, 128, 3, 4) \
+  X(128, 128, 3, 8) X(128, 64, 3, 8) X(64, 64, 3, 8) X(64, 128, 3, 8)
+
 void dtp_gemm_init() {  // raise the dynamic-LDS limit once, outside any stream capture
 #define SET_ATTR(BM, BN, NS) \
   (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8);
@@ -614,6 +663,14 @@ void dtp_gemm_init() {  // raise the dynamic-LDS limit once, outside any stream 
   (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8);
   FOR_ALL_KH2(SET_ATTR2)
 #undef SET_ATTR2
+#define SET_ATTR3(BM, BN, NS, LW) \
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS, 1, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8);
+  FOR_ALL_LW(SET_ATTR3)
+#undef SET_ATTR3
+}
+
+static void lw_variant(int tile, int* ns, int* lw) {  // tile 40..47
+  *ns = 3; *lw = tile < 44 ? 4 : 8;
 }
 
 // 20 / 21: gemm_wide_kernel 256 x 256 / 256 x 320 (gemm_wide.hip).  24..27: gemm_fp8_kernel, the shapes of ids 0..3 (gemm_fp8.hip).
@@ -627,6 +684,7 @@ bool dtp_gemm_tile_dims(int tile, int* bm, int* bn, int* ns) {
   if (tile >= 24 && tile < 28) { *bm = sm[tile & 3]; *bn = sn[tile & 3]; *ns = 2; return true; }     // gemm_fp8_kernel
   if (tile == 28) { *bm = 256; *bn = 256; *ns = 2; return true; }                                    // gemm_fp8_kernel, 8 waves
   if (tile >= 32 && tile < 40) { *bm = sm[tile & 3]; *bn = sn[tile & 3]; *ns = 2 + ((tile - 32) >> 2); return true; }  // gemm_kernel, 8 waves (KH = 2)
+  if (tile >= 40 && tile < 48) { int lw; *bm = sm[tile & 3]; *bn = sn[tile & 3]; lw_variant(tile, ns, &lw); return true; }  // gemm_kernel with loader waves
   return false;
 }
 
@@ -702,8 +760,16 @@ int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
 #undef DISPATCH
 #define DISPATCH2(BM, BN, NS) \
   if (rc < 0 && bm == BM && bn == BN && ns == NS) rc = launch_tile<BM, BN, NS, 2>(p, s);
-  if (tile >= 32) { FOR_ALL_KH2(DISPATCH2) }
+  if (tile >= 32 && tile < 40) { FOR_ALL_KH2(DISPATCH2) }
 #undef DISPATCH2
+  if (tile >= 40) {
+    int lns, lw;
+    lw_variant(tile, &lns, &lw);
+#define DISPATCH3(BM, BN, NS, LW) \
+    if (rc < 0 && bm == BM && bn == BN && lns == NS && lw == LW) rc = launch_tile<BM, BN, NS, 1, LW>(p, s);
+    FOR_ALL_LW(DISPATCH3)
+#undef DISPATCH3
+  }
   if (rc != DTP_OK) { dtp_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
   if (p.splits > 1 && !(p.flags & GF_NOREDUCE)) return dtp_launch_splitk_reduce(p, s);
   return DTP_OK;

@@ -61,6 +61,70 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int ldx, float* __res
   }
 }
 
+// pass 1 with the split-K reduce of the producing conv folded in (feature maps above 256 pixels, where the single-launch
+// gn_reduce_fused_kernel does not apply): same block shape and partial sums as gn_stats_kernel, but the 8-channel chunk of a pixel
+// is first SUMMED from the conv's fp32 slabs (+ bias, + residual), rounded to fp16 and written out as the conv output -- the
+// statistics are taken from exactly those rounded values.  One launch and one pass over the fp16 tensor fewer than reduce kernel
+// + gn_stats_kernel.
+__global__ void gn_stats_reduce_kernel(const float* __restrict__ part, int splits, long long slab, int ldp, const float* __restrict__ bias,
+                                       const f16* __restrict__ R, int ldr, f16* __restrict__ c_out, int ldc, float* __restrict__ partial,
+                                       int HW, int C, int cpg, int groups, int pix_per_chunk) {
+  __shared__ float red[1024 * 4];
+  const int nch = C >> 3;
+  const int cc = threadIdx.x % nch, prow = threadIdx.x / nch, rows = blockDim.x / nch;
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int c0 = cc * 8;
+  const int g0 = c0 / cpg;
+  const int split = min(8, (g0 + 1) * cpg - c0);
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  const int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
+  f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = {0.f, 0.f, 0.f, 0.f};
+  if (bias) { bv0 = *(const f32x4*)(bias + c0); bv1 = *(const f32x4*)(bias + c0 + 4); }
+  for (int p = p0 + prow; p < p1; p += rows) {
+    const size_t row = (size_t)b * HW + p;
+    const float* pp = part + row * ldp + c0;
+    f32x4 a0 = *(const f32x4*)pp, a1 = *(const f32x4*)(pp + 4);
+    for (int z = 1; z < splits; ++z) {
+      const f32x4 t0 = *(const f32x4*)(pp + (size_t)z * slab), t1 = *(const f32x4*)(pp + (size_t)z * slab + 4);
+      a0 += t0; a1 += t1;
+    }
+    a0 += bv0; a1 += bv1;
+    if (R) {
+      const f16x8 r = *(const f16x8*)(R + row * ldr + c0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a0[e] += (float)r[e]; a1[e] += (float)r[4 + e]; }
+    }
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h[e] = (f16)a0[e]; h[4 + e] = (f16)a1[e]; }
+    *(f16x8*)(c_out + row * ldc + c0) = h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = (float)h[e];
+      if (e < split) { s0 += f; q0 += f * f; } else { s1 += f; q1 += f * f; }
+    }
+  }
+  red[threadIdx.x * 4 + 0] = s0;
+  red[threadIdx.x * 4 + 1] = q0;
+  red[threadIdx.x * 4 + 2] = s1;
+  red[threadIdx.x * 4 + 3] = q1;
+  __syncthreads();
+  float* out = partial + ((size_t)b * nchunk + chunk) * groups * 2;
+  for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+    float s = 0.f, q = 0.f;
+    const int cfirst = (g * cpg) >> 3, clast = ((g + 1) * cpg - 1) >> 3;
+    for (int c = cfirst; c <= clast; ++c) {
+      const int sel = ((c * 8) / cpg == g) ? 0 : 2;
+      for (int r = 0; r < rows; ++r) {
+        s += red[(r * nch + c) * 4 + sel];
+        q += red[(r * nch + c) * 4 + sel + 1];
+      }
+    }
+    out[g * 2] = s;
+    out[g * 2 + 1] = q;
+  }
+}
+
 // pass 2: every block first combines the per-chunk partials of its batch item into (mean, rstd) for all
 // groups (8 lanes per group, fixed order -> deterministic), then normalises (+ SiLU) 8-channel chunks.
 __global__ __launch_bounds__(1024) void gn_apply_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy,
@@ -386,6 +450,13 @@ size_t dtp_groupnorm_ws_bytes(int B, int HW, int C, int groups) {
   return (size_t)B * gn_chunks(HW) * groups * 2 * sizeof(float);
 }
 
+// the two-launch GroupNorm; with `rd` the statistics pass also sums the producing conv's split-K slabs and writes x
+struct GnReduceSrc {
+  const float* part; int splits; long long slab; int ldp; const float* bias; const f16* R; int ldr;
+};
+static int groupnorm_two_pass(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, float* ws, int B, int HW, int C,
+                              int groups, float eps, int silu, const GnReduceSrc* rd, hipStream_t s);
+
 int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, float* ws, int B,
                          int HW, int C, int groups, float eps, int silu, hipStream_t s) {
   if ((C & 7) || (C % groups) || (ldx & 7) || (ldy & 7) || groups > 64) {
@@ -408,6 +479,12 @@ int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* ga
       return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
     }
   }
+  return groupnorm_two_pass(x, ldx, y, ldy, gamma, beta, ws, B, HW, C, groups, eps, silu, nullptr, s);
+}
+
+static int groupnorm_two_pass(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, float* ws, int B, int HW, int C,
+                              int groups, float eps, int silu, const GnReduceSrc* rd, hipStream_t s) {
+  const int cpg = C / groups;
   const int nch = C / 8;
   const int nchunk = gn_chunks(HW);
   const int ppc = (HW + nchunk - 1) / nchunk;
@@ -418,7 +495,11 @@ int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* ga
   if (rows < 1) rows = 1;
   const int threads = nch * rows;
   if (threads > 1024) { dtp_set_error("groupnorm: C too large"); return DTP_ERR_ARG; }
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(threads), 0, s, x, ldx, ws, HW, C, cpg, groups, ppc);
+  if (rd)
+    hipLaunchKernelGGL(gn_stats_reduce_kernel, dim3(nchunk, B), dim3(threads), 0, s, rd->part, rd->splits, rd->slab, rd->ldp, rd->bias, rd->R, rd->ldr,
+                       (f16*)x, ldx, ws, HW, C, cpg, groups, ppc);
+  else
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(threads), 0, s, x, ldx, ws, HW, C, cpg, groups, ppc);
   const long long per_batch = (long long)HW * nch;
   // one fat block per CU (tools/diag_gn.py sweep: 1024 threads x <= 256 blocks is 5-7 % ahead of 256 x 768): every block
   // re-reduces the partials of its batch item first, so fewer blocks re-read them less often
@@ -447,10 +528,16 @@ bool dtp_reduce_groupnorm_supported(int HW, int C, int groups) {
 
 int dtp_launch_reduce_groupnorm(const float* part, int splits, long long slab, int ldp, const float* bias, const f16* R, int ldr,
                                 f16* c_out, int ldc, f16* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
-                                int groups, float eps, int silu, hipStream_t s) {
-  if (!dtp_reduce_groupnorm_supported(HW, C, groups) || (ldp & 3) || (ldc & 7) || (ldy & 7) || (R && (ldr & 7))) {
+                                int groups, float eps, int silu, float* stats_ws, hipStream_t s) {
+  if ((ldp & 3) || (ldc & 7) || (ldy & 7) || (R && (ldr & 7)) || (C & 7) || (C % groups) || groups > 64 || C / groups < 4 ||
+      (C / groups < 8 && C / groups != 4)) {
     dtp_set_error("reduce+groupnorm: HW=%d C=%d groups=%d unsupported", HW, C, groups);
     return DTP_ERR_ARG;
+  }
+  if (!dtp_reduce_groupnorm_supported(HW, C, groups)) {  // large maps: reduce folded into the statistics pass, then the apply pass
+    if (!stats_ws) { dtp_set_error("reduce+groupnorm: the two-pass form needs the statistics workspace"); return DTP_ERR_ARG; }
+    const GnReduceSrc rd = {part, splits, slab, ldp, bias, R, ldr};
+    return groupnorm_two_pass(c_out, ldc, y, ldy, gamma, beta, stats_ws, B, HW, C, groups, eps, silu, &rd, s);
   }
   const int cpg = C / groups;
   int G = 1;

@@ -8,7 +8,7 @@
 
 #include "engine.h"
 
-int get_unet_prog(Ctx* c, int N, UNetProg** out);
+int get_unet_prog(Ctx* c, int N, int dupB, UNetProg** out);
 int get_enc_prog(Ctx* c, int B, VaeEncProg** out);
 int get_dec_prog(Ctx* c, int B, VaeDecProg** out);
 int launch_vae_sample(Ctx* c, const float* mom, const float* eps, float* out, int B, float scale, hipStream_t s);
@@ -385,8 +385,9 @@ int dtp_stamp_slots(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, c
   VaeEncProg* enc;
   VaeDecProg* dec;
   StampBufs* sb;
-  if (tg_evals > 0) RC(get_unet_prog(c, 3 * B, &u3));
-  if (tg_evals < E) RC(get_unet_prog(c, 2 * B, &u2));
+  // branches 0 (uncond) and 1 (cond) see identical samples: the programs evaluate the UNet prefix once for both (unet.hip, struct Dup)
+  if (tg_evals > 0) RC(get_unet_prog(c, 3 * B, B, &u3));
+  if (tg_evals < E) RC(get_unet_prog(c, 2 * B, B, &u2));
   RC(get_enc_prog(c, 2 * B, &enc));
   RC(get_dec_prog(c, B, &dec));
   RC(get_bufs(c, B, &sb));
@@ -560,6 +561,15 @@ int dtp_set_option(dtp_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "use_graph")) { c->use_graph = value != 0; return DTP_OK; }
   if (!strcmp(name, "autotune")) { c->autotune = value != 0; return DTP_OK; }
   if (!strcmp(name, "check_finite")) { c->check_finite = value != 0; return DTP_OK; }
+  if (!strcmp(name, "dedupe_prefix")) {  // programs are keyed by it: switching only affects which (cached) program a stamp uses
+    c->dedupe_prefix = value != 0;
+    for (auto& g : c->graphs) {  // captured stages hold the old program's launches
+      if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+      if (g.second.graph) (void)hipGraphDestroy(g.second.graph);
+    }
+    c->graphs.clear();
+    return DTP_OK;
+  }
   if (!strcmp(name, "fp8_linear")) {
     if (!c->unet_progs.empty() && c->fp8_linear != (value != 0)) {
       dtp_set_error("dtp_set_option: fp8_linear must be chosen before the first UNet program is built");

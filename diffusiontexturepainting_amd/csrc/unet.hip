@@ -162,8 +162,29 @@ int ensure_temb(Ctx* c, const std::vector<float>& timesteps) {
   return DTP_OK;
 }
 
-static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up, T& out, const T* dst = nullptr) {
-  const int C = x.C, S = x.H * x.W, N = x.B;
+// sub-batch view: samples [first, first + count) of an NHWC tensor
+static T samples(const T& t, int first, int count) {
+  T v = t;
+  v.p += (size_t)first * t.H * t.W * t.ld;
+  v.B = count;
+  return v;
+}
+
+// De-duplicated prefix (Dup): the uncond and cond branches of a stamp feed the UNet IDENTICAL samples (inpaint_pipeline.py:115,136,
+// stable_diffusion_pipeline.py:423: cat([latents] * 3), cat([mask, mask, ctx_mask]), cat([ml, ml, ctx_ml])) and first differ in
+// encoder_hidden_states, i.e. at the first cross-attention.  Everything before it -- conv_in, down_blocks.0.resnets.0, the first
+// transformer's GroupNorm / proj_in / self-attention -- is evaluated for samples [dupB, N) only (batch order [uncond | cond | tg]:
+// one contiguous range) and the uncond rows [0, dupB) of the three tensors that live on (the conv_in skip, the transformer input,
+// the self-attention output with its LayerNorm statistics) are filled by ONE row-copy launch: bit-identical results.
+struct Dup {
+  int B = 0;       // samples filled by duplication (0 = off)
+  T x_full;        // the transformer input for all N samples (x below is its [B, N) view)
+  T skip_full;     // the conv_in skip view for all N samples (channel slice of a concat buffer)
+};
+
+static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up, T& out, const T* dst = nullptr, const Dup* dup = nullptr) {
+  const int dB = dup ? dup->B : 0;
+  const int C = x.C, S = x.H * x.W, N = x.B + dB;  // x holds the samples that are really evaluated up to the cross-attention
   T t, y, n1, qkv, a, y2, n2, y3, n3, f;
   RC(b.gn(x, w.gn, 1e-6f, false, t));
   // LayerNorms are folded into their consumer GEMMs; the row statistics ride on the producer's epilogue
@@ -176,17 +197,44 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
   T q = qkv, k = qkv, v = qkv;
   q.C = k.C = v.C = C;
   k.p += C; v.p += 2 * C;
-  RC(b.attention(q, k, v, 8, S, S, N, a));
+  RC(b.attention(q, k, v, 8, S, S, x.B, a));
   b.release(qkv);
   a.B = x.B; a.H = x.H; a.W = x.W;
-  RC(b.alloc_stats(x.rows(), C, st2));
-  RC(b.linear(a, w.out1, &y, 0, y2, &st2));
+  RC(b.alloc_stats((long long)N * S, C, st2));
+  T xin = x;  // the block input for all N samples (residual of the last GEMM)
+  if (dB > 0) {
+    y2 = b.alloc(N, x.H, x.W, C);
+    if (!y2.p) return DTP_ERR_HIP;
+    const T y2s = samples(y2, dB, x.B);
+    st2.rows_total = N * S; st2.row_off = dB * S;
+    T y2v;
+    RC(b.linear(a, w.out1, &y, 0, y2v, &st2, nullptr, &y2s));
+    st2.M = N * S;
+    // one launch: uncond rows <- cond rows of the skip, the block input, the self-attention output and its row statistics
+    CopySegs cs = {};
+    auto seg = [&](const void* src, void* dstp, long long rows, long long row_bytes, long long sstride, long long dstride) {
+      cs.src[cs.n] = (const char*)src; cs.dst[cs.n] = (char*)dstp; cs.rows[cs.n] = rows; cs.row_bytes[cs.n] = row_bytes;
+      cs.src_stride[cs.n] = sstride; cs.dst_stride[cs.n] = dstride; ++cs.n;
+    };
+    const long long rB = (long long)dB * S;
+    const T &sk = dup->skip_full, &xf = dup->x_full;
+    seg(sk.p + rB * sk.ld, sk.p, rB, (long long)sk.C * 2, (long long)sk.ld * 2, (long long)sk.ld * 2);
+    seg(xf.p + rB * xf.ld, xf.p, rB, (long long)xf.C * 2, (long long)xf.ld * 2, (long long)xf.ld * 2);
+    seg(y2.p + rB * y2.ld, y2.p, rB, (long long)C * 2, (long long)y2.ld * 2, (long long)y2.ld * 2);
+    seg(st2.buf + rB * 2, st2.buf, st2.parts, rB * 8, (long long)N * S * 8, (long long)N * S * 8);
+    double bytes = 0;
+    for (int i = 0; i < cs.n; ++i) bytes += 2.0 * cs.rows[i] * cs.row_bytes[i];
+    b.push(PK_ELEM, 0.0, bytes, [=](hipStream_t s, int) { return dtp_launch_copy_rows(cs, s); }, "dup uncond<-cond rows=" + std::to_string(rB));
+    xin = dup->x_full;
+  } else {
+    RC(b.linear(a, w.out1, &y, 0, y2, &st2));
+  }
   b.release(a); b.release(y);
   // Cross-attention over 14 context tokens: softmax_j(LN2(y2) Wq'^T K^T) V Wo^T collapses to two grouped GEMMs against
   // per-sample matrices prepared once per stamp (UNetProg::xW1 / xW2): scores + group softmax, then the value-output product.
   {
     const int i = w.kv_index, Cp = (C + 127) / 128 * 128;
-    T pm = b.alloc(x.B, x.H, x.W, 128);  // probabilities [rows][8 heads x 16 (14 valid)]
+    T pm = b.alloc(N, x.H, x.W, 128);  // probabilities [rows][8 heads x 16 (14 valid)]
     if (!pm.p) return DTP_ERR_HIP;
     GemmParams g = {};
     g.A = y2.p; g.W = up.xW1[i]; g.C = pm.p;
@@ -197,8 +245,8 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
     if (st2.buf && st2.parts > 0 && st2.M == N * S) { g.st_in = st2.buf; g.st_parts = st2.parts; g.st_rows = N * S; }
     RC(push_gemm(b.c, b.prog, g, -1, (double)C, nullptr));
     b.release_stats(st2);
-    RC(b.alloc_stats(x.rows(), C, st3));
-    y3 = b.alloc(x.B, x.H, x.W, C);
+    RC(b.alloc_stats((long long)N * S, C, st3));
+    y3 = b.alloc(N, x.H, x.W, C);
     if (!y3.p) return DTP_ERR_HIP;
     GemmParams h = {};
     h.A = pm.p; h.W = up.xW2[i]; h.C = y3.p;
@@ -218,18 +266,18 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
     const ConvW& wm = w.ff2_proj;
     if (wm.K != f.C + y3.C || wm.cout != C) { dtp_set_error("transformer: merged ff2/proj_out weight mismatch"); return DTP_ERR_ARG; }
     if (dst) {
-      if (dst->C != C || dst->rows() != x.rows()) { dtp_set_error("transformer: destination view mismatch"); return DTP_ERR_ARG; }
+      if (dst->C != C || dst->rows() != (long long)N * S) { dtp_set_error("transformer: destination view mismatch"); return DTP_ERR_ARG; }
       out = *dst;
     } else {
-      out = b.alloc(x.B, x.H, x.W, C);
+      out = b.alloc(N, x.H, x.W, C);
       if (!out.p) return DTP_ERR_HIP;
     }
     GemmParams g = {};
     g.A = f.p; g.lda = f.ld; g.A2 = y3.p; g.lda2 = y3.ld; g.Cin2 = y3.C;
     g.W = wm.w; g.ldw = wm.ldw; g.nkb = wm.ldw / 64;
-    g.M = (int)x.rows(); g.N = C; g.K = wm.K;
+    g.M = N * S; g.N = C; g.K = wm.K;
     g.C = out.p; g.ldc = out.ld;
-    g.bias = wm.b; g.R = x.p; g.ldr = x.ld;
+    g.bias = wm.b; g.R = xin.p; g.ldr = xin.ld;
     g.flags = GF_BIAS | GF_RESID;
     if (b.fp8 && wm.w8) {
       GemmParams q = g;
@@ -242,7 +290,7 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
   return DTP_OK;
 }
 
-int build_unet_prog(Ctx* c, int N, UNetProg& up) {
+int build_unet_prog(Ctx* c, int N, int dupB, UNetProg& up) {
   const UNetW& u = c->unet;
   const int h = c->h;
   up.N = N;
@@ -334,14 +382,32 @@ int build_unet_prog(Ctx* c, int N, UNetProg& up) {
   }
   int sk = 0;  // next skip to produce
   T x;
-  RC(b.conv3(x0, u.conv_in, 1, 1, false, h, h, nullptr, -1, x, 0, nullptr, 0, nullptr, &skipv[sk++]));
+  if (dupB > 0) {  // de-duplicated prefix: conv_in on samples [dupB, N) only (struct Dup)
+    const T x0s = samples(x0, dupB, N - dupB), sk0s = samples(skipv[sk], dupB, N - dupB);
+    RC(b.conv3(x0s, u.conv_in, 1, 1, false, h, h, nullptr, -1, x, 0, nullptr, 0, nullptr, &sk0s));
+    ++sk;
+  } else {
+    RC(b.conv3(x0, u.conv_in, 1, 1, false, h, h, nullptr, -1, x, 0, nullptr, 0, nullptr, &skipv[sk++]));
+  }
   for (int i = 0; i < 4; ++i) {
     for (int j = 0; j < 2; ++j) {
       T y;
       if (i < 3) {
-        RC(b.resnet(x, u.down_res[i][j], 1e-5f, true, y));
         T z;
-        RC(transformer(b, y, u.down_xf[i][j], up, z, &skipv[sk++]));
+        if (dupB > 0 && i == 0 && j == 0) {
+          Dup dup;
+          dup.B = dupB;
+          dup.skip_full = skipv[0];
+          dup.x_full = b.alloc(N, x.H, x.W, u.down_res[0][0].c2.cout);
+          if (!dup.x_full.p) return DTP_ERR_HIP;
+          const T ys = samples(dup.x_full, dupB, N - dupB);
+          RC(b.resnet(x, u.down_res[i][j], 1e-5f, true, y, &ys));
+          RC(transformer(b, y, u.down_xf[i][j], up, z, &skipv[sk++], &dup));
+          y = dup.x_full;  // released below
+        } else {
+          RC(b.resnet(x, u.down_res[i][j], 1e-5f, true, y));
+          RC(transformer(b, y, u.down_xf[i][j], up, z, &skipv[sk++]));
+        }
         b.release(y);
         x = z;
       } else {
@@ -416,11 +482,13 @@ int launch_nhwc_f32_to_nchw(const float* x, float* y, int B, int C, int HW, int 
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
-int get_unet_prog(Ctx* c, int N, UNetProg** out) {
-  auto it = c->unet_progs.find(N);
+int get_unet_prog(Ctx* c, int N, int dupB, UNetProg** out) {
+  if (!c->dedupe_prefix || dupB >= N) dupB = 0;
+  const int key = N * 64 + dupB;
+  auto it = c->unet_progs.find(key);
   if (it == c->unet_progs.end()) {
-    UNetProg& up = c->unet_progs[N];
-    RC(build_unet_prog(c, N, up));
+    UNetProg& up = c->unet_progs[key];
+    RC(build_unet_prog(c, N, dupB, up));
     *out = &up;
     return DTP_OK;
   }
@@ -436,7 +504,7 @@ extern "C" int dtp_unet(dtp_ctx* ctx, const float* sample, float timestep, const
   if (N < 1 || N > 3 * c->maxB) { dtp_set_error("dtp_unet: batch %d outside 1..%d", N, 3 * c->maxB); return DTP_ERR_ARG; }
   HIP_CHECK(hipSetDevice(c->device));
   UNetProg* up;
-  RC(get_unet_prog(c, N, &up));
+  RC(get_unet_prog(c, N, 0, &up));  // engine-level call: arbitrary samples, nothing to de-duplicate
   const int hw = c->h * c->h;
   HIP_CHECK(hipStreamSynchronize(s));
   RC(ensure_temb(c, {timestep}));

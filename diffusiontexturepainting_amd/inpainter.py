@@ -208,9 +208,9 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
         check(self._lib.dtp_profile(self._h, int(enable)), "dtp_profile")
 
     def profile_rows(self):
-        rows = (_lib.ProfRow * 32)()
+        rows = (_lib.ProfRow * 64)()
         n = C.c_int()
-        check(self._lib.dtp_profile_rows(self._h, rows, 32, C.byref(n)), "dtp_profile_rows")
+        check(self._lib.dtp_profile_rows(self._h, rows, 64, C.byref(n)), "dtp_profile_rows")
         return [dict(kernel=_lib.PROF_KINDS[r.kind], launches=r.launches, ms=r.ms, flops=r.flops, bytes=r.bytes)
                 for r in rows[: n.value]]
 

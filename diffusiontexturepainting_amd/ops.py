@@ -154,6 +154,16 @@ def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False):
     return y
 
 
+def reduce_groupnorm(part, gamma, beta, bias=None, resid=None, groups=32, eps=1e-5, silu=False):
+    """part f32 [splits, B, HW, C] split-K slabs of a conv -> (conv output f16 [B,HW,C], GroupNorm(+SiLU) of it)."""
+    lib = _lib.load()
+    sp, b, hw, c = part.shape
+    out, y = torch.empty(b, hw, c, dtype=torch.float16, device=part.device), torch.empty(b, hw, c, dtype=torch.float16, device=part.device)
+    check(lib.dtp_op_reduce_groupnorm(ptr(part), sp, ptr(bias), ptr(resid), ptr(out), ptr(y), ptr(gamma), ptr(beta), b, hw, c, groups, eps, int(silu),
+                                      _stream()), "reduce_groupnorm")
+    return out, y
+
+
 def layernorm(x, gamma, beta, eps=1e-5):
     lib = _lib.load()
     c = x.shape[-1]

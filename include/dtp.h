@@ -203,6 +203,14 @@ int dtp_op_pack_conv(const float* w, void* out, int Cout, int Cin, int Cin_pad, 
 int dtp_op_pack_conv_cb(const float* w, void* out, int Cout, int Cin, int ldw, dtp_stream s);
 int dtp_op_groupnorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
                      int groups, float eps, int silu, dtp_stream s);
+/* measured ceilings of this GPU (bench.py roofline.peak_measured): dense fp16 MFMA TFLOP/s with random operands on every SIMD, and
+ * the HBM GB/s (read + write) of a 512 MiB float4 copy; blocking, ~50 ms */
+int dtp_op_measure_peaks(double* mfma_f16_tflops, double* hbm_copy_gbs);
+/* split-K slabs part f32 [splits][B*HW][C] (+ bias[C], + resid f16 [B*HW][C]) -> conv_out f16 [B*HW][C] and y = GroupNorm(conv_out)
+ * (+SiLU): the reduce of a split 3x3 conv folded into the GroupNorm that consumes it (models.py:250-302 GroupNorm+Swish plugin
+ * behind a conv); one launch for HW <= 256, reduce-in-statistics + apply above */
+int dtp_op_reduce_groupnorm(const float* part, int splits, const float* bias, const void* resid, void* conv_out, void* y, const float* gamma,
+                            const float* beta, int B, int HW, int C, int groups, float eps, int silu, dtp_stream s);
 int dtp_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int rows, int C,
                      float eps, dtp_stream s);
 int dtp_op_attention(const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo, int B, int H,

@@ -164,3 +164,26 @@ def test_config1_512_20steps_matches_cpu_oracle(model512, weights):
         with open(os.environ["DTP_FULLSIZE_JSON"], "w") as f:
             f.write(json.dumps(rec) + "\n")
     assert rec["max_abs_pixel_err"] <= 1e-2 and rec["unet_evals"] == 19
+
+
+def test_deduplicated_prefix_is_bit_identical(weights):
+    """The uncond and cond branches feed the UNet identical samples (inpaint_pipeline.py:115,136): the shared prefix (conv_in ...
+    the first self-attention) is evaluated once and duplicated.  With the SAME kernel choices (autotuner off: the heuristic tiles
+    do not depend on the row count at this size) a stamp must not change by a single bit -- both launch programs (3 and 2 branches:
+    texture guidance is cut off mid-loop), B = 1 and B = 2 (N = 6 is also what B = 3 with 2 branches would give)."""
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    outs = {}
+    for dedupe in (1, 0):
+        m = MI355ConditionalInpainter(512, device=0, weights=weights[0], max_batch=2)
+        m.set_option("autotune", 0)
+        m.set_option("dedupe_prefix", dedupe)
+        for b in (1, 2):
+            canvas, brush, cond, uncond, lat, eps = _inputs(b, 512, 700 + b)
+            m.set_conditioning(cond, uncond, brush)
+            st = dict(steps=5, context_pad=150, tg_steps=2, cfg_weight=2.0, tg_weight=1.0)
+            outs[(dedupe, b)] = (m.generate_raw(canvas, latents=lat, vae_eps=eps, **st).cpu(), m.stamp_info()["graph_nodes"])
+        del m
+    for b in (1, 2):
+        assert torch.equal(outs[(1, b)][0], outs[(0, b)][0]), (outs[(1, b)][0] - outs[(0, b)][0]).abs().max()
+        assert torch.isfinite(outs[(1, b)][0]).all() and outs[(1, b)][0].std() > 1e-3
+        assert outs[(1, b)][1] == outs[(0, b)][1] + 4  # one row-copy launch per evaluation (4 evaluations), nothing else changes

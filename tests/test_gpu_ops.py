@@ -36,7 +36,7 @@ def close(got, ref, tol=2e-3):
 
 
 @pytest.mark.parametrize("m,n,k", [(300, 320, 320), (4096, 640, 1280), (192, 1280, 2560), (77, 768, 768), (14, 1280, 768)])
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 20, 21, 32, 33, 34, 35, 36, 37, 38, 39])  # shape + 4 * (stages - 2); 16.. = 256-wide tiles; 20 / 21 = 8-wave wide tiles; 32.. = 8-wave (k-split) twins of 0..7
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 20, 21, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47])  # shape + 4 * (stages - 2); 16.. = 256-wide tiles; 20 / 21 = 8-wave wide tiles; 32.. = 8-wave (k-split) twins of 0..7; 40.. = loader-wave variants (4 / 8 DMA-only waves)
 def test_gemm_dense(ops, m, n, k, tile):
     a, w = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5)
     bias = torch.randn(n, generator=torch.Generator().manual_seed(3))
@@ -47,7 +47,7 @@ def test_gemm_dense(ops, m, n, k, tile):
     close(got, ref)
 
 
-@pytest.mark.parametrize("tile", [-1, 34, 36])
+@pytest.mark.parametrize("tile", [-1, 34, 36, 42, 47])
 @pytest.mark.parametrize("splits", [2, 5, 16])
 def test_gemm_splitk(ops, splits, tile):
     m, n, k = 192, 1280, 11520
@@ -71,7 +71,7 @@ def test_gemm_asymmetric_identity(ops):
     close(got, w.float().t(), tol=1e-6)
 
 
-@pytest.mark.parametrize("m,c,tile", [(512, 320, -1), (100, 1280, -1), (700, 320, 20), (300, 640, 20), (512, 320, 32), (100, 1280, 39), (300, 640, 36)])
+@pytest.mark.parametrize("m,c,tile", [(512, 320, -1), (100, 1280, -1), (700, 320, 20), (300, 640, 20), (512, 320, 32), (100, 1280, 39), (300, 640, 36), (512, 320, 40), (100, 1280, 47)])
 def test_gemm_geglu(ops, m, c, tile):
     a, w = rnd(m, c, seed=8), rnd(8 * c, c, seed=9, scale=c ** -0.5)
     bias = torch.randn(8 * c, generator=torch.Generator().manual_seed(10)) * 0.1
@@ -94,7 +94,8 @@ def test_gemm_geglu(ops, m, c, tile):
 @pytest.mark.parametrize("m,c,n,tile,geglu", [(300, 320, 960, -1, False), (100, 1280, 1280, 6, False), (513, 640, 5120, -1, True),
                                              (64, 768, 768, 3, False), (513, 640, 5120, 17, True), (300, 320, 960, 18, False),
                                              (513, 640, 5120, 20, True), (300, 320, 960, 21, False), (700, 320, 960, 20, False),
-                                             (300, 320, 960, 34, False), (513, 640, 5120, 32, True), (64, 768, 768, 39, False), (100, 1280, 1280, 37, False)])
+                                             (300, 320, 960, 34, False), (513, 640, 5120, 32, True), (64, 768, 768, 39, False), (100, 1280, 1280, 37, False),
+                                             (300, 320, 960, 42, False), (513, 640, 5120, 44, True), (100, 1280, 1280, 41, False)])
 def test_gemm_layernorm_fold(ops, m, c, n, tile, geglu):
     """LN(x) W^T + b computed from the RAW x: W carries gamma, bias carries W.beta, statistics in-kernel."""
     from diffusiontexturepainting_amd._lib import GF_BIAS, GF_GEGLU
@@ -120,7 +121,7 @@ def test_gemm_layernorm_fold(ops, m, c, n, tile, geglu):
     close(got, ref, tol=3e-3)
 
 
-@pytest.mark.parametrize("tile", [-1, 2, 5, 8, 33, 34, 39])
+@pytest.mark.parametrize("tile", [-1, 2, 5, 8, 33, 34, 39, 41, 46])
 def test_gemm_batched_group_softmax(ops, tile):
     """Grouped GEMM (one weight matrix per batch entry) + LayerNorm fold + softmax over groups of 16 columns (14 valid):
     the first half of the algebraically fused cross-attention (scores against 14 context tokens, 8 heads)."""
@@ -158,7 +159,7 @@ def test_gemm_batched_residual(ops):
 
 @pytest.mark.parametrize("m,k1,k2,n,tile,splits", [(300, 1280, 320, 320, -1, 0), (130, 256, 64, 192, 2, 3), (768, 640, 128, 640, 17, 1), (64, 128, 128, 128, 5, 2),
                                                    (768, 640, 128, 640, 21, 1), (600, 1280, 320, 320, 20, 1), (300, 1280, 320, 320, 32, 1), (130, 256, 64, 192, 38, 3),
-                                                   (768, 640, 128, 640, 35, 2)])
+                                                   (768, 640, 128, 640, 35, 2), (300, 1280, 320, 320, 43, 1), (130, 256, 64, 192, 46, 3)])
 def test_gemm_two_activation_matrices(ops, m, k1, k2, n, tile, splits):
     """[f | r] . [W1 | W2]^T with f and r in separate buffers: how ff.net.2 (+residual) and proj_out run as one GEMM."""
     f, r = rnd(m, k1, seed=30), rnd(m, k2, seed=31)
@@ -207,7 +208,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [-1, 5, 8, 10, 16, 19, 20, 21, 32, 34, 37, 39])
+@pytest.mark.parametrize("tile", [-1, 5, 8, 10, 16, 19, 20, 21, 32, 34, 37, 39, 40, 42, 45, 47])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3x3(ops, case, tile):
     b, h, w, cin, cout, stride, pad, ups, out_hw = case
@@ -235,7 +236,8 @@ def test_conv3x3(ops, case, tile):
 @pytest.mark.parametrize("b,h,cin,cin2,cout,tile,splits", [(2, 16, 64, 128, 64, -1, 0), (3, 8, 320, 640, 320, 5, 0), (1, 8, 128, 64, 256, 8, 3),
                                                            (3, 16, 320, 640, 320, 17, 2), (1, 16, 128, 64, 256, 18, 0),
                                                            (3, 16, 320, 640, 320, 21, 1), (1, 16, 128, 64, 256, 20, 1),
-                                                           (3, 8, 320, 640, 320, 33, 0), (1, 8, 128, 64, 256, 36, 3), (2, 16, 64, 128, 64, 38, 2)])
+                                                           (3, 8, 320, 640, 320, 33, 0), (1, 8, 128, 64, 256, 36, 3), (2, 16, 64, 128, 64, 38, 2),
+                                                           (3, 8, 320, 640, 320, 41, 0), (1, 8, 128, 64, 256, 46, 3), (3, 16, 320, 640, 320, 44, 2)])
 def test_conv3x3_fused_shortcut(ops, b, h, cin, cin2, cout, tile, splits):
     """ResBlock tail as ONE contraction: conv3x3(t) + conv1x1(x) + biases = [im2col(t) | x] . [W3 | W1]^T."""
     t, x = rnd(b, h, h, cin, seed=24), rnd(b, h, h, cin2, seed=25)
@@ -315,6 +317,33 @@ def test_groupnorm(ops, b, hw, c, silu, eps):
     close(got, ref)
 
 
+@pytest.mark.parametrize("b,hw,c,splits,silu,bias,resid", [(3, 64, 1280, 8, True, True, False), (3, 256, 1280, 4, True, True, True),   # one launch (HW <= 256)
+                                                           (3, 1024, 640, 2, True, True, False), (2, 1024, 640, 3, False, False, True),  # reduce rides in the
+                                                           (1, 4096, 320, 2, True, True, True), (2, 1600, 960, 2, True, False, False)])  # statistics pass
+def test_reduce_groupnorm(ops, b, hw, c, splits, silu, bias, resid):
+    """The split-K reduce of a conv folded into the GroupNorm that consumes it: conv output = fp16(sum of slabs + bias + residual)
+    BIT-exactly (the same fp32 additions in the same order), normalised tensor against torch on that rounded tensor."""
+    g = torch.Generator().manual_seed(45)
+    part = torch.randn(splits, b, hw, c, generator=g) * 0.7
+    bv = torch.randn(c, generator=g) if bias else None
+    rv = rnd(b, hw, c, seed=46) if resid else None
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    acc = part[0].clone()
+    for z in range(1, splits):
+        acc += part[z]
+    if bias:
+        acc += bv
+    if resid:
+        acc += rv.float()
+    conv = acc.half()
+    ref = F.group_norm(conv.float().permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    out, y = ops.reduce_groupnorm(part.cuda(), gamma.cuda(), beta.cuda(), bias=bv.cuda() if bias else None, resid=rv.cuda() if resid else None, silu=silu)
+    assert torch.equal(out.cpu(), conv)
+    close(y, ref)
+
+
 @pytest.mark.parametrize("rows,c", [(1000, 320), (333, 640), (64, 1280), (14, 768), (5, 2048)])
 def test_layernorm(ops, rows, c):
     x = rnd(rows, c, seed=50) * 1.5 + 0.3
@@ -363,7 +392,7 @@ def test_softmax_rows(ops):
 
 
 @pytest.mark.parametrize("m,n,k,tile", [(300, 320, 320, -1), (700, 640, 640, 0), (700, 640, 640, 20), (130, 1280, 320, 2), (513, 320, 1280, 20),
-                                        (700, 640, 640, 32), (130, 1280, 320, 38), (513, 320, 1280, 35)])
+                                        (700, 640, 640, 32), (130, 1280, 320, 38), (513, 320, 1280, 35), (700, 640, 640, 40), (130, 1280, 320, 46)])
 def test_gemm_row_statistics_feed_the_layernorm_fold(ops, m, n, k, tile):
     """Producer GEMM emits per-row (sum, sumsq) partials of its fp16 output (one per N tile); a LayerNorm-folded consumer
     that takes them must equal the consumer that computes the statistics itself -- and the fp32 LayerNorm reference."""
