@@ -100,6 +100,17 @@ def pmc_traffic(batch):
             "traffic_source": "profiles/r02_pmc_unet_traffic.json", "traffic_kernel_source_hash": t["kernel_source_hash"]}
 
 
+def measured_peaks():
+    """Ceilings measured on THIS box right before the timed region (< 0.1 s): the dense fp16 MFMA rate with random operands on every
+    SIMD (the chip clocks to its power budget, ~1.55 GHz under MFMA load, so the vendor's 2.5 PFLOP/s is not reachable by any
+    kernel) and the float4 copy bandwidth of HBM -- csrc/peaks.hip."""
+    import ctypes as C
+    from diffusiontexturepainting_amd import _lib
+    tf, gb = C.c_double(), C.c_double()
+    _lib.check(_lib.load().dtp_op_measure_peaks(C.byref(tf), C.byref(gb)), "dtp_op_measure_peaks")
+    return tf.value, gb.value
+
+
 def time_stamps(model, batch, res, ddim_steps, n, warm, seed):
     """ms per stamp batch (inputs resident, torch.cuda.synchronize on both sides) of `n` timed batches after `warm` untimed ones."""
     from diffusiontexturepainting_amd import synthetic
@@ -313,6 +324,7 @@ def main():
     if world > 1 and rank == 0:
         D.barrier()
     gatherer = D.PatchGatherer(n_total, (a.res, a.res, 3), torch.uint8, dev, rank, world) if distributed else None
+    peak_tf, peak_gbs = measured_peaks() if rank == 0 else (None, None)
 
     def one_step():
         out = model._stamp(canvas, settings, composite=True, latents=lat, vae_eps=eps, output_u8=True)
@@ -354,6 +366,10 @@ def main():
             "bound": "mfma", "kernel": "gemm_kernel<BM,BN,NS> + gemm_wide_kernel<BM,BN> + conv_halo_kernel<TH,TW,BN> (implicit-GEMM conv/linear, all instantiations)",
             "achieved": g_fl / (g_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": g_fl / (g_ms * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS,
+            "peak_measured": peak_tf, "frac_of_measured": g_fl / (g_ms * 1e-3) / 1e12 / peak_tf,
+            "peak_measured_note": "v_mfma_f32_32x32x16_f16 issue rate, one wave per SIMD on every CU, random operands, measured on this box "
+                                  "before the timed region (csrc/peaks.hip); hbm_peak_measured = float4 copy, read + write bytes",
+            "hbm_peak": PEAK_HBM_GBS, "hbm_peak_measured": peak_gbs,
             "launches": g_n, "avg_launch_us": g_ms * 1e3 / g_n, "share_of_gpu_time": g_ms / tot_ms,
             "algorithmic_tflop_per_step": g_fl / 1e12,
             "algorithmic_bytes_per_launch": sum(r["bytes"] for r in gem) / g_n,
@@ -365,7 +381,10 @@ def main():
             "kernels": [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["ms"], 3),
                          "avg_us": round(r["ms"] * 1e3 / r["launches"], 2), "share": round(r["ms"] / tot_ms, 4),
                          "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1),
-                         "algo_GBps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in rows],
+                         "algo_GBps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1),
+                         # HBM-bound classes (GroupNorm, LayerNorm, elementwise): algorithmic bytes per second against the measured copy rate
+                         **({"hbm_frac_of_measured": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9 / peak_gbs, 4)} if r["flops"] == 0 and r["bytes"] > 0 else {})}
+                        for r in rows],
         }
     cpu = None
     if not a.no_cpu_baseline and rank == 0 and world == 1:

@@ -174,6 +174,20 @@ int dtp_op_reduce_groupnorm(const float* part, int splits, const float* bias, co
                                      groups, eps, silu, g_ops.ws, (hipStream_t)s);
 }
 
+int dtp_op_gn_fold_weights(const void* x, const void* W, int ldw, const float* bias, const float* gamma, const float* beta, int B, int HW, int C,
+                           int Nout, int groups, float eps, void* Wout, float* bias_out, dtp_stream s) {
+  std::lock_guard<std::mutex> lk(g_ops_mu);
+  int rc = ops_init();
+  if (rc) return rc;
+  rc = ops_ws(dtp_groupnorm_ws_bytes(B, HW, C, groups));
+  if (rc) return rc;
+  rc = dtp_launch_groupnorm_stats((const f16*)x, C, g_ops.ws, B, HW, C, groups, nullptr, (hipStream_t)s);
+  if (rc) return rc;
+  const int rows = (Nout + 127) / 128 * 128;
+  return dtp_launch_gn_fold_weights((const f16*)W, ldw, bias, gamma, beta, g_ops.ws, B, HW, C, Nout, groups, eps, (f16*)Wout, (long long)rows * ldw, bias_out,
+                                    rows, (hipStream_t)s);
+}
+
 int dtp_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int rows, int C,
                      float eps, dtp_stream s) {
   return dtp_launch_layernorm((const f16*)x, ldx, (f16*)y, ldy, gamma, beta, rows, C, eps, (hipStream_t)s);

@@ -316,7 +316,10 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
 
 int dtp_launch_attention(const AttnParams& pin, hipStream_t s) {
   AttnParams p = pin;
-  static const int prio_env = [] { const char* e = getenv("DTP_ATTN_PRIO"); return e ? atoi(e) : 0; }();
+  // s_setprio(1) around the QK^T (bit 0) and PV (bit 1) MFMA clusters: the co-resident workgroups of a CU are at different phases, so
+  // the scheduler has something to arbitrate (level-0 launch 118.1 -> 114.7 us at batch 1, 85.5 -> 80.9 us on the two de-duplicated
+  // samples, neutral at batch 8; tools/diag_attn.py).  $DTP_ATTN_PRIO overrides (0 = off) for A/B.
+  static const int prio_env = [] { const char* e = getenv("DTP_ATTN_PRIO"); return e ? atoi(e) : 3; }();
   p.prio = prio_env;
   if ((p.D & 7) || (p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.ldo & 3) || p.Skv < 1 || p.Sq < 1) {
     dtp_set_error("attention: D=%d ldq=%d ldk=%d ldv=%d ldo=%d unsupported", p.D, p.ldq, p.ldk, p.ldv, p.ldo);

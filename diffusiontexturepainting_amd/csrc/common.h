@@ -61,6 +61,30 @@ static __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
+// Sum n (value, value) pairs spaced `stride` floats apart, IN ORDER, with the loads issued eight at a time before their additions.
+// A `for (q) s += p[q * stride]` loop chains one memory round trip per term (hipcc does not pipeline a runtime trip count): with
+// 5-20 partial sums per row that chain was microseconds of pure latency in front of every LayerNorm-folded GEMM and GroupNorm apply.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ void sum_pairs_strided(const float* __restrict__ p, size_t stride, int n, float& s1, float& s2) {
+  s1 = 0.f; s2 = 0.f;
+  int q = 0;
+  for (; q + 8 <= n; q += 8) {
+    f32x2 t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = *(const f32x2*)(p + (size_t)(q + e) * stride);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1 += t[e][0]; s2 += t[e][1]; }
+  }
+  if (q < n) {
+    f32x2 t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = *(const f32x2*)(p + (size_t)(q + (q + e < n ? e : 0)) * stride);  // clamped: always a valid address
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (q + e < n) { s1 += t[e][0]; s2 += t[e][1]; }
+  }
+}
+
 #define DTP_WAVE 64
 
 #define HIP_CHECK(x)                                                                        \
@@ -151,6 +175,15 @@ bool dtp_reduce_groupnorm_supported(int HW, int C, int groups);
 int dtp_launch_reduce_groupnorm(const float* part, int splits, long long slab, int ldp, const float* bias, const f16* R, int ldr,
                                 f16* c_out, int ldc, f16* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
                                 int groups, float eps, int silu, float* stats_ws, hipStream_t s);
+// the split-K slabs of the conv that produced a GroupNorm's input (its reduce rides in the statistics pass)
+struct GnReduceSrc {
+  const float* part; int splits; long long slab; int ldp; const float* bias; const f16* R; int ldr;
+};
+// GroupNorm (no activation) folded into the Linear that consumes it: statistics pass (+ optional split-K reduce), then per-sample
+// weights / biases for a grouped GEMM on the raw tensor (norm.hip gn_fold_weights_kernel)
+int dtp_launch_groupnorm_stats(const f16* x, int ldx, float* ws, int B, int HW, int C, int groups, const GnReduceSrc* rd, hipStream_t s);
+int dtp_launch_gn_fold_weights(const f16* W, int ldw, const float* bias, const float* gamma, const float* beta, const float* ws, int B, int HW,
+                               int C, int Nout, int groups, float eps, f16* Wout, long long w_bs, float* bias_out, int bias_bs, hipStream_t s);
 int dtp_launch_layernorm(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, int rows, int C,
                          float eps, hipStream_t s);
 int dtp_launch_softmax_rows(const f16* x, int ldx, f16* y, int ldy, int rows, int cols, float scale, hipStream_t s);

@@ -280,7 +280,21 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { bv[e] = t0[e]; bv[4 + e] = t1[e]; }
   }
-  for (int idx = tid; idx < BM * NC; idx += 256) {
+  // residual rows three iterations ahead (three-register ring, unconditional loads from clamped pixels): see gemm_conv.hip
+  constexpr int EIT = BM * NC / 256;
+  const bool pre_r = (fl & GF_RESID) && n + 8 <= p.N;
+  auto load_r = [&](int it) {
+    const int r = (tid + min(it, EIT - 1) * 256) / NC;
+    const int y = min(y0 + r / TW, H - 1), x = min(x0 + r % TW, W - 1);
+    return *(const f16x8*)(p.R + (((size_t)img * H + y) * W + x) * p.ldr + n);
+  };
+  f16x8 r0 = {0, 0, 0, 0, 0, 0, 0, 0}, r1 = r0, r2 = r0;
+  if (pre_r) { r0 = load_r(0); r1 = load_r(1); r2 = load_r(2); }
+  int eit = 0;
+  for (int idx = tid; idx < BM * NC; idx += 256, ++eit) {
+    const f16x8 rcur = r0;
+    r0 = r1; r1 = r2;
+    if (pre_r) r2 = load_r(eit + 3);
     const int ml = idx / NC;
     bool ok;
     const size_t m = row_m(ml, ok);
@@ -290,9 +304,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = (float)v[e] + bv[e];
     if (fl & GF_RESID) {
-      const f16x8 r = *(const f16x8*)(p.R + m * p.ldr + n);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] += (float)r[e];
+      for (int e = 0; e < 8; ++e) x[e] += (float)rcur[e];
     }
     f16x8 o;
 #pragma unroll

@@ -241,6 +241,7 @@ struct Ctx {
   int* finite_flag = nullptr;     // device: set to 1 by the post-loop finiteness check ("check_finite" option)
   bool check_finite = false;
   bool dedupe_prefix = true;      // uncond and cond branches share the UNet prefix up to the first cross-attention ($DTP_NO_DEDUPE=1: off, A/B)
+  bool fold_gn_linear = true;     // transformer GroupNorm folded into per-sample proj_in weights at HW >= 1024 ($DTP_NO_FOLD_GN=1: off, A/B)
   bool fuse_reduce_gn = true;     // fold a split-K conv's reduce into the GroupNorm that consumes it ($DTP_NO_FUSE_REDUCE_GN=1: off, A/B)
   bool fp8_linear = false;        // UNet transformer Linears / 1x1 convs on the fp8 MX MFMA (configs[4]); fixed once a UNet program exists
   bool fp8_attention = false;     // UNet self-attention on the fp8 MX MFMA (BASELINE configs[4]); fixed once a UNet program exists
@@ -303,6 +304,9 @@ struct Builder {
   T alloc(int B, int H, int W, int C);
   void release(const T& t);
   int gn(const T& x, const NormW& n, float eps, bool silu, T& y);
+  bool claim_reduce(const T& x, GemmParams& gp, int& bias_step_off);
+  bool gn_linear_supported(const T& x, const ConvW& w) const;
+  int gn_linear(const T& x, const NormW& n, float eps, const ConvW& w, T& y, RowStats* emit);
   int ln(const T& x, const NormW& n, T& y);
   // conv3x3; bias_step_off >= 0 selects the per-step bias slice from the temb table instead of w.b
   int conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, int Ho, int Wo, const T* resid, int bias_step_off,

@@ -336,6 +336,23 @@ T Builder::alloc(int B, int H, int W, int C) {
 }
 void Builder::release(const T& t) { ctx_pool_put(c, t.p); }
 
+// The producer of x was a split-K conv whose reduce has not run yet: take the reduce over (the GroupNorm-side kernel sums the slabs
+// and writes x itself).  Re-pushes the conv with GF_NOREDUCE and returns its parameters.
+bool Builder::claim_reduce(const T& x, GemmParams& gp, int& bias_step_off) {
+  const LastGemm lg = prog->last_gemm;
+  const int keep = GF_BIAS | GF_RESID | GF_CONV3 | GF_UPS2 | GF_MFAST;
+  if (!(c->fuse_reduce_gn && lg.valid && lg.p.splits > 1 && (f16*)lg.p.C == x.p && lg.p.ldc == x.ld && lg.p.M == (int)x.rows() && lg.p.N == x.C &&
+        !(lg.p.flags & ~keep) && lg.p.batch <= 1 && (x.C & 7) == 0))
+    return false;
+  gp = lg.p;
+  gp.flags |= GF_NOREDUCE;
+  prog->ops[lg.op_index] = Op();  // rebuilt below through the profiling wrapper
+  prog->ops.pop_back();
+  prog_push(c, prog, lg.kind, lg.flops, lg.bytes, make_gemm_op(c, gp, lg.tile, lg.bias_step_off), lg.label + " (reduce in gn)");
+  bias_step_off = lg.bias_step_off;
+  return true;
+}
+
 int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
   y = alloc(x.B, x.H, x.W, x.C);
   if (!y.p) return DTP_ERR_HIP;
@@ -343,17 +360,9 @@ int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
   cc->ws_need = std::max(cc->ws_need, dtp_groupnorm_ws_bytes(x.B, x.H * x.W, x.C, 32));
   const T xx = x, yy = y;
   const NormW nn = n;
-  // The producer was a split-K conv whose reduce has not run yet: sum its slabs here (writes x AND y, one launch fewer)
-  const LastGemm lg = prog->last_gemm;
-  const int keep = GF_BIAS | GF_RESID | GF_CONV3 | GF_UPS2 | GF_MFAST;
-  if (cc->fuse_reduce_gn && lg.valid && lg.p.splits > 1 && (f16*)lg.p.C == x.p && lg.p.ldc == x.ld && lg.p.M == (int)x.rows() && lg.p.N == x.C &&
-      !(lg.p.flags & ~keep) && lg.p.batch <= 1 && (x.C & 7) == 0) {
-    GemmParams gp = lg.p;
-    gp.flags |= GF_NOREDUCE;
-    prog->ops[lg.op_index] = Op();  // rebuilt below through the profiling wrapper
-    prog->ops.pop_back();
-    prog_push(cc, prog, lg.kind, lg.flops, lg.bytes, make_gemm_op(cc, gp, lg.tile, lg.bias_step_off), lg.label + " (reduce in gn)");
-    const int bso = lg.bias_step_off;
+  GemmParams gp;
+  int bso = -1;
+  if (claim_reduce(x, gp, bso)) {
     const bool has_bias = (gp.flags & GF_BIAS) != 0;
     // small maps: one launch does it all; large maps: the reduce rides in the statistics pass, whose partial sums live behind the slabs
     const size_t slab_bytes = (dtp_gemm_workspace_bytes(gp) + 255) & ~(size_t)255;
@@ -369,6 +378,66 @@ int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
   push(PK_GN, 0.0, 4.0 * (double)xx.rows() * xx.C, [=](hipStream_t s, int) {
     return dtp_launch_groupnorm(xx.p, xx.ld, yy.p, yy.ld, nn.g, nn.b, cc->ws, xx.B, xx.H * xx.W, xx.C, 32, eps, silu ? 1 : 0, s);
   }, "gn B=" + std::to_string(x.B) + " HW=" + std::to_string(x.H * x.W) + " C=" + std::to_string(x.C));
+  return DTP_OK;
+}
+
+// GroupNorm (no activation) + the Linear / 1x1 conv that consumes it, with the normalisation folded into per-sample weights
+// (norm.hip gn_fold_weights_kernel): statistics pass (+ the producer's split-K reduce) -> fold -> ONE grouped GEMM on the raw tensor.
+// The apply pass and the normalised tensor do not exist.  Same three launches as stats + apply + GEMM, but the middle one touches
+// N * C * C weights instead of reading and writing the whole activation tensor.
+bool Builder::gn_linear_supported(const T& x, const ConvW& w) const {
+  const int HW = x.H * x.W, C = x.C;
+  return c->fold_gn_linear && HW >= 1024 && w.taps == 1 && w.K == C && w.ldw == C && (C % 64) == 0 && C <= 2048 && (C % 32) == 0 && !w.lns &&
+         !(fp8 && w.w8) && C / 32 >= 8;
+}
+
+int Builder::gn_linear(const T& x, const NormW& n, float eps, const ConvW& w, T& y, RowStats* emit) {
+  Ctx* cc = c;
+  const int HW = x.H * x.W, C = x.C, N = x.B, Cp = (w.cout + 127) / 128 * 128;
+  GemmParams gp;
+  int bso = -1;
+  const bool claimed = claim_reduce(x, gp, bso);
+  const size_t slab_bytes = claimed ? ((dtp_gemm_workspace_bytes(gp) + 255) & ~(size_t)255) : 0;
+  cc->ws_need = std::max(cc->ws_need, slab_bytes + dtp_groupnorm_ws_bytes(N, HW, C, 32));
+  void *pw = nullptr, *pb = nullptr;
+  RC(ctx_pool_get(cc, (size_t)N * Cp * w.ldw * sizeof(f16), &pw));
+  RC(ctx_pool_get(cc, (size_t)N * Cp * sizeof(float), &pb));
+  f16* Wf = (f16*)pw;
+  float* bf = (float*)pb;
+  const T xx = x;
+  const NormW nn = n;
+  const ConvW ww = w;
+  const bool has_bias = claimed && (gp.flags & GF_BIAS) != 0;
+  push(PK_GN, 0.0, 2.0 * (double)xx.rows() * C, [=](hipStream_t s, int step) {
+    float* part_ws = (float*)((char*)cc->ws + slab_bytes);
+    if (claimed) {
+      GnReduceSrc rd;
+      rd.part = cc->ws; rd.splits = gp.splits; rd.slab = (long long)gp.M * gp.N; rd.ldp = gp.N;
+      rd.bias = !has_bias ? nullptr : (bso >= 0 ? cc->temb_table + (size_t)step * cc->unet.temb_total + bso : gp.bias);
+      rd.R = (gp.flags & GF_RESID) ? gp.R : nullptr; rd.ldr = gp.ldr;
+      return dtp_launch_groupnorm_stats(xx.p, xx.ld, part_ws, N, HW, C, 32, &rd, s);
+    }
+    return dtp_launch_groupnorm_stats(xx.p, xx.ld, part_ws, N, HW, C, 32, nullptr, s);
+  }, std::string(claimed ? "reduce+gn-stats" : "gn-stats") + " B=" + std::to_string(N) + " HW=" + std::to_string(HW) + " C=" + std::to_string(C));
+  push(PK_GN, 0.0, 2.0 * (double)N * w.cout * C * 2, [=](hipStream_t s, int) {
+    return dtp_launch_gn_fold_weights(ww.w, ww.ldw, ww.b, nn.g, nn.b, (const float*)((char*)cc->ws + slab_bytes), N, HW, C, ww.cout, 32, eps, Wf,
+                                      (long long)Cp * ww.ldw, bf, Cp, s);
+  }, "gn-fold B=" + std::to_string(N) + " C=" + std::to_string(C) + " N=" + std::to_string(w.cout));
+  y = alloc(x.B, x.H, x.W, w.cout);
+  if (!y.p) return DTP_ERR_HIP;
+  GemmParams g = {};
+  g.A = x.p; g.lda = x.ld; g.W = Wf; g.ldw = w.ldw; g.nkb = w.ldw / 64;
+  g.M = HW; g.N = w.cout; g.K = w.K;
+  g.C = y.p; g.ldc = y.ld;
+  g.bias = bf; g.flags = GF_BIAS;
+  g.batch = N; g.a_bs = (long long)HW * x.ld; g.w_bs = (long long)Cp * w.ldw; g.c_bs = (long long)HW * y.ld; g.bias_bs = Cp;
+  if (emit && emit->buf) {
+    g.flags |= GF_ROWSTATS; g.st_out = emit->buf; g.st_rows = N * HW;
+    if (emit->rows_total > 0) { g.st_out = emit->buf + (size_t)emit->row_off * 2; g.st_rows = emit->rows_total; }
+  }
+  RC(push_gemm(cc, prog, g, -1, (double)w.K, (emit && emit->buf) ? emit : nullptr));
+  ctx_pool_put(cc, pw);
+  ctx_pool_put(cc, pb);
   return DTP_OK;
 }
 
@@ -776,6 +845,7 @@ int dtp_create(int device, int resolution, int max_batch, dtp_ctx** out) {
   tune_cache_load(c);
   if (const char* e = getenv("DTP_NO_FUSE_REDUCE_GN")) c->fuse_reduce_gn = !(e[0] && e[0] != '0');
   if (const char* e = getenv("DTP_NO_DEDUPE")) c->dedupe_prefix = !(e[0] && e[0] != '0');
+  if (const char* e = getenv("DTP_NO_FOLD_GN")) c->fold_gn_linear = !(e[0] && e[0] != '0');
   *out = (dtp_ctx*)c;
   return DTP_OK;
 }

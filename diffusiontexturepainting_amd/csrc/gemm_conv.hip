@@ -44,7 +44,9 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // every ~25-40 cycles and stalls nobody.  Same LDS image, same ring, same counted-vmcnt protocol: the loader waits for ITS
 // k-block t, everyone meets at the barrier, the loader then refills the slot the consumers have just left.  Loader waves end
 // after the last k-block (s_barrier only counts the waves that are still alive), the epilogue belongs to the consumers.
-template <int BM, int BN, int NS, int KH = 1, int LW = 0>
+// CONV: compile-time operand mode (3x3 implicit GEMM vs dense rows).  As a run-time flag the tap bookkeeping of the conv path sat in
+// the k-loop of every dense launch as well (~100 scalar / branch instructions per k-block around 4-16 MFMAs).
+template <int BM, int BN, int NS, int KH = 1, int LW = 0, bool CONV = false>
 __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmParams pin) {
   GemmParams p = pin;
   const int st_rows = p.st_rows > 0 ? p.st_rows : p.M;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
   // chunk slot ^ ((r>>1)&7).
   const int lrow = dwave * 8 + (lane >> 3);
   const int kc = (((lane & 7) ^ ((lrow >> 1) & 7)) << 3);  // element offset inside the k-block
-  const bool conv = (p.flags & GF_CONV3) != 0;
+  constexpr bool conv = CONV;
   const int ups = (p.flags & GF_UPS2) ? 1 : 0;
   const int Hlim = p.Hi << ups, Wlim = p.Wi << ups;
 
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const int m = m0 + i * RPR + lrow;
-    if (conv) {
+    if constexpr (conv) {
       const int hw = p.Ho * p.Wo;
       const int b = m / hw, rem = m - b * hw;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
   }
 
   int tap = 0, cch = 0, cur_tap = -1;  // conv: current tap / channel offset of this thread's chunk; tap cached in a_row[]
-  if (conv) {
+  if constexpr (conv) {
     const int k = kb0 * 64 + kc;
     if (k < 9 * p.Cin) { tap = k / p.Cin; cch = k - tap * p.Cin; }
     else { tap = 9; cch = k - 9 * p.Cin; }  // inside the fused 1x1-shortcut tail
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
   bool dense_tail = false;
   const int dense_k1 = p.K - p.Cin2;  // dense two-operand GEMM: first column read from A2
   auto prep = [&](int kb) {
-    if (conv) {
+    if constexpr (conv) {
       // The tap (ky,kx) only changes every Cin/64 k-blocks: the per-row bounds test and pixel address are
       // recomputed then and cached in a_row[]; in between only the channel offset advances.
       if (tap != cur_tap) {
@@ -231,11 +233,7 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
     for (int r = tid; r < BM; r += NT) {
       const int m = m0 + r;
       float s1 = 0.f, s2 = 0.f;
-      if (m < p.M)
-        for (int q = 0; q < p.st_parts; ++q) {
-          s1 += p.st_in[((size_t)q * st_rows + st_m0 + m) * 2];
-          s2 += p.st_in[((size_t)q * st_rows + st_m0 + m) * 2 + 1];
-        }
+      if (m < p.M) sum_pairs_strided(p.st_in + ((size_t)st_m0 + m) * 2, (size_t)st_rows * 2, p.st_parts, s1, s2);
       const float mean = s1 / (float)p.K;
       rowst[2 * r] = mean;
       rowst[2 * r + 1] = rsqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + p.ln_eps);
@@ -494,7 +492,22 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
     }
   }
   static_assert((BM * NC) % NT == 0 && NT % NC == 0, "every lane runs every iteration and keeps its column chunk");
-  for (int idx = tid; idx < BM * NC; idx += NT) {
+  // Residual rows are fetched THREE iterations ahead (a three-register ring, unconditional loads from clamped rows): inside the loop
+  // body a load -> wait -> store sequence per iteration chained one L2 / HBM round trip per row block -- 8-16 of them behind each
+  // other on the 128- and 256-row tiles (the stores to C may alias R for all the compiler knows, so it never hoisted them).
+  constexpr int EIT = BM * NC / NT;
+  const bool pre_r = (fl & GF_RESID) && full && vec_ok;
+  auto load_r = [&](int it) {
+    const int mr = min(m0 + (tid + min(it, EIT - 1) * NT) / NC, p.M - 1);
+    return *(const f16x8*)(p.R + (size_t)mr * p.ldr + n);
+  };
+  f16x8 r0 = {0, 0, 0, 0, 0, 0, 0, 0}, r1 = r0, r2 = r0;
+  if (pre_r) { r0 = load_r(0); r1 = load_r(1); r2 = load_r(2); }
+  int eit = 0;
+  for (int idx = tid; idx < BM * NC; idx += NT, ++eit) {
+    const f16x8 rcur = r0;
+    r0 = r1; r1 = r2;
+    if (pre_r) r2 = load_r(eit + 3);
     const int ml = idx / NC;
     const int m = m0 + ml;
     const bool active = (m < p.M) && (n < p.N);
@@ -543,10 +556,9 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
         for (int e = 0; e < 8; ++e) x[e] *= inv;
       }
       if (full && vec_ok) {
-        if (fl & GF_RESID) {
-          const f16x8 r = *(const f16x8*)(p.R + (size_t)m * p.ldr + n);
+        if (fl & GF_RESID) {  // full && vec_ok here, i.e. pre_r: the row was prefetched
 #pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] += (float)r[e];
+          for (int e = 0; e < 8; ++e) x[e] += (float)rcur[e];
         }
         f16x8 o;
 #pragma unroll
@@ -582,22 +594,54 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
   }
 }
 
-// Sum split-K slabs and apply the same (non-GEGLU) epilogue.
+// Sum split-K slabs and apply the same (non-GEGLU) epilogue.  VEC: four consecutive columns per thread (N % 4 == 0, fp16 output
+// with 8-byte aligned rows); the loads of four slabs are issued before their additions (in slab order: the sum is the plain
+// loop's, bit for bit) -- a load -> add chain per slab made these launches one memory round trip per slab long.
+template <bool VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+  constexpr int W = VEC ? 4 : 1;
   const long long total = (long long)p.M * p.N;
   const int fl = p.flags;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * W; i < total; i += (long long)gridDim.x * 256 * W) {
     const int m = (int)(i / p.N), n = (int)(i - (long long)m * p.N);
-    float x = 0.f;
-    for (int z = 0; z < p.splits; ++z) x += p.part[(size_t)z * total + i];
-    if (fl & GF_BIAS) x += p.bias[n];
-    if (fl & GF_BIAS_M) x += p.bias[m];
-    if (fl & GF_GELU) x = gelu_erf(x);
-    if (fl & GF_QUICKGELU) x = x / (1.0f + __expf(-1.702f * x));
-    if (fl & GF_SILU) x = x / (1.0f + __expf(-x));
-    if (fl & GF_RESID) x += (float)p.R[(size_t)m * p.ldr + n];
-    if (fl & GF_OUT_F32) ((float*)p.C)[(size_t)m * p.ldc + n] = x;
-    else ((f16*)p.C)[(size_t)m * p.ldc + n] = (f16)x;
+    float x[W];
+    if constexpr (VEC) {
+      const float* pp = p.part + i;
+      f32x4 a = *(const f32x4*)pp;
+      int z = 1;
+      for (; z + 3 < p.splits; z += 4) {
+        const f32x4 t0 = *(const f32x4*)(pp + (size_t)z * total), t1 = *(const f32x4*)(pp + (size_t)(z + 1) * total);
+        const f32x4 t2 = *(const f32x4*)(pp + (size_t)(z + 2) * total), t3 = *(const f32x4*)(pp + (size_t)(z + 3) * total);
+        a += t0; a += t1; a += t2; a += t3;
+      }
+      for (; z < p.splits; ++z) a += *(const f32x4*)(pp + (size_t)z * total);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = a[e];
+    } else {
+      x[0] = 0.f;
+      for (int z = 0; z < p.splits; ++z) x[0] += p.part[(size_t)z * total + i];
+    }
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+      if (fl & GF_BIAS) x[e] += p.bias[n + e];
+      if (fl & GF_BIAS_M) x[e] += p.bias[m];
+      if (fl & GF_GELU) x[e] = gelu_erf(x[e]);
+      if (fl & GF_QUICKGELU) x[e] = x[e] / (1.0f + __expf(-1.702f * x[e]));
+      if (fl & GF_SILU) x[e] = x[e] / (1.0f + __expf(-x[e]));
+    }
+    if constexpr (VEC) {
+      if (fl & GF_RESID) {
+        const f16x4 r = *(const f16x4*)(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] += (float)r[e];
+      }
+      const f16x4 o = {(f16)x[0], (f16)x[1], (f16)x[2], (f16)x[3]};
+      *(f16x4*)((f16*)p.C + (size_t)m * p.ldc + n) = o;
+    } else {
+      if (fl & GF_RESID) x[0] += (float)p.R[(size_t)m * p.ldr + n];
+      if (fl & GF_OUT_F32) ((float*)p.C)[(size_t)m * p.ldc + n] = x[0];
+      else ((f16*)p.C)[(size_t)m * p.ldc + n] = (f16)x[0];
+    }
   }
 }
 
@@ -625,14 +669,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
   if (lane == 0) { p.st_out[(size_t)m * 2] = s1; p.st_out[(size_t)m * 2 + 1] = s2; }
 }
 
-template <int BM, int BN, int NS, int KH = 1, int LW = 0>
-int launch_tile(const GemmParams& p, hipStream_t s) {
+template <int BM, int BN, int NS, int KH, int LW, bool CONV>
+int launch_tile_mode(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   constexpr int lds = NS * (BM + BN) * 128 + BM * 8;  // + per-row LayerNorm statistics
   static_assert(lds - BM * 8 >= BM * (BN + 8) * 2, "staging tile must fit in the pipeline buffers");
   static_assert(lds <= 160 * 1024, "LDS budget");
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS, KH, LW>), dim3(tiles, p.batch > 1 ? p.batch : 1, p.splits), dim3(256 * KH + 64 * LW), lds, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS, KH, LW, CONV>), dim3(tiles, p.batch > 1 ? p.batch : 1, p.splits), dim3(256 * KH + 64 * LW), lds, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
+
+template <int BM, int BN, int NS, int KH = 1, int LW = 0>
+int launch_tile(const GemmParams& p, hipStream_t s) {
+  return (p.flags & GF_CONV3) ? launch_tile_mode<BM, BN, NS, KH, LW, true>(p, s) : launch_tile_mode<BM, BN, NS, KH, LW, false>(p, s);
 }
 
 }  // namespace
@@ -656,15 +705,18 @@ int launch_tile(const GemmParams& p, hipStream_t s) {
 
 void dtp_gemm_init() {  // raise the dynamic-LDS limit once, outside any stream capture
 #define SET_ATTR(BM, BN, NS) \
-  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS, 1, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8); \
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS, 1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8);
   FOR_ALL_VARIANTS(SET_ATTR)
 #undef SET_ATTR
 #define SET_ATTR2(BM, BN, NS) \
-  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS, 2, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8); \
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8);
   FOR_ALL_KH2(SET_ATTR2)
 #undef SET_ATTR2
 #define SET_ATTR3(BM, BN, NS, LW) \
-  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS, 1, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS, 1, LW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8); \
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, NS, 1, LW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NS*(BM + BN) * 128 + BM * 8);
   FOR_ALL_LW(SET_ATTR3)
 #undef SET_ATTR3
 }
@@ -785,8 +837,12 @@ int dtp_launch_splitk_reduce(const GemmParams& p, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
   }
   long long total = (long long)p.M * p.N;
-  int blocks = (int)((total + 255) / 256);
+  const bool vec = (p.N & 3) == 0 && !(p.flags & GF_OUT_F32) && (p.ldc & 3) == 0 && (!(p.flags & GF_RESID) || (p.ldr & 3) == 0) &&
+                   (((uintptr_t)p.C | (uintptr_t)p.R) & 7) == 0;
+  int blocks = (int)((total / (vec ? 4 : 1) + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+  if (blocks < 1) blocks = 1;
+  if (vec) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }

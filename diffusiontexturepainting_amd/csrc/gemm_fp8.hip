@@ -118,11 +118,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_fp8_kernel(const GemmParams 
     for (int r = tid; r < BM; r += NT) {
       const int m = m0 + r;
       float s1 = 0.f, s2 = 0.f;
-      if (m < p.M)
-        for (int q = 0; q < p.st_parts; ++q) {
-          s1 += p.st_in[((size_t)q * st_rows + m) * 2];
-          s2 += p.st_in[((size_t)q * st_rows + m) * 2 + 1];
-        }
+      if (m < p.M) sum_pairs_strided(p.st_in + (size_t)m * 2, (size_t)st_rows * 2, p.st_parts, s1, s2);
       const float mean = s1 / (float)p.K;
       rowst[2 * r] = mean;
       rowst[2 * r + 1] = rsqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + p.ln_eps);

@@ -168,11 +168,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_wide_kernel(const GemmParams
     for (int r = tid; r < BM; r += NT) {
       const int m = m0 + r;
       float s1 = 0.f, s2 = 0.f;
-      if (m < p.M)
-        for (int q = 0; q < p.st_parts; ++q) {
-          s1 += p.st_in[((size_t)q * st_rows + m) * 2];
-          s2 += p.st_in[((size_t)q * st_rows + m) * 2 + 1];
-        }
+      if (m < p.M) sum_pairs_strided(p.st_in + (size_t)m * 2, (size_t)st_rows * 2, p.st_parts, s1, s2);
       const float mean = s1 / (float)p.K;
       rowst[2 * r] = mean;
       rowst[2 * r + 1] = rsqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + p.ln_eps);
@@ -346,7 +342,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_wide_kernel(const GemmParams
         for (int x = 0; x < 4; ++x) { lv[x] = t0[x]; lv[4 + x] = t1[x]; }
       }
     }
-    for (int idx = tid; idx < ROWS_EP * NC + (NT - NTE); idx += NTE) {
+    // residual rows three iterations ahead (three-register ring, unconditional loads from clamped rows): see gemm_conv.hip
+    const bool pre_r = (fl & GF_RESID) && col_ok;
+    auto load_r = [&](int it) {
+      const int mr = min(mbase + min((tid + it * NTE) / NC, ROWS_EP - 1), p.M - 1);
+      return *(const f16x8*)(p.R + (size_t)mr * p.ldr + n);
+    };
+    f16x8 r0 = {0, 0, 0, 0, 0, 0, 0, 0}, r1 = r0, r2 = r0;
+    if (pre_r) { r0 = load_r(0); r1 = load_r(1); r2 = load_r(2); }
+    int eit = 0;
+    for (int idx = tid; idx < ROWS_EP * NC + (NT - NTE); idx += NTE, ++eit) {
+      const f16x8 rcur = r0;
+      r0 = r1; r1 = r2;
+      if (pre_r) r2 = load_r(eit + 3);
       const int ml = idx / NC, m = mbase + ml;
       const bool active = col_ok && ml < ROWS_EP && m < p.M;
       float s1 = 0.f, s2 = 0.f;
@@ -374,10 +382,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_wide_kernel(const GemmParams
 #pragma unroll
           for (int k = 0; k < 8; ++k) x[k] = x[k] / (1.0f + __expf(-x[k]));
         }
-        if (fl & GF_RESID) {
-          const f16x8 r = *(const f16x8*)(p.R + (size_t)m * p.ldr + n);
+        if (fl & GF_RESID) {  // active implies col_ok, i.e. pre_r: the row was prefetched
 #pragma unroll
-          for (int k = 0; k < 8; ++k) x[k] += (float)r[k];
+          for (int k = 0; k < 8; ++k) x[k] += (float)rcur[k];
         }
         f16x8 o;
 #pragma unroll

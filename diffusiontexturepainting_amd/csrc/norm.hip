@@ -16,6 +16,30 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Sum of the split-K slabs of one 8-channel chunk, z = 0 .. splits-1 IN ORDER (bit-identical to the plain loop), with the loads of
+// four slabs issued before their additions: a loop of load -> add -> load chains one memory round trip per slab (8-16 slabs of
+// cold fp32 data: the whole launch time of the small-map kernels), hipcc does not software-pipeline a runtime trip count.
+__device__ __forceinline__ void slab_sum8(const float* __restrict__ pp, int splits, long long slab, f32x4& a0, f32x4& a1) {
+  a0 = *(const f32x4*)pp;
+  a1 = *(const f32x4*)(pp + 4);
+  int z = 1;
+  for (; z + 3 < splits; z += 4) {
+    const float* q = pp + (size_t)z * slab;
+    const f32x4 t0 = *(const f32x4*)q, t1 = *(const f32x4*)(q + 4);
+    const f32x4 t2 = *(const f32x4*)(q + slab), t3 = *(const f32x4*)(q + slab + 4);
+    const f32x4 t4 = *(const f32x4*)(q + 2 * slab), t5 = *(const f32x4*)(q + 2 * slab + 4);
+    const f32x4 t6 = *(const f32x4*)(q + 3 * slab), t7 = *(const f32x4*)(q + 3 * slab + 4);
+    a0 += t0; a1 += t1;
+    a0 += t2; a1 += t3;
+    a0 += t4; a1 += t5;
+    a0 += t6; a1 += t7;
+  }
+  for (; z < splits; ++z) {
+    const f32x4 t0 = *(const f32x4*)(pp + (size_t)z * slab), t1 = *(const f32x4*)(pp + (size_t)z * slab + 4);
+    a0 += t0; a1 += t1;
+  }
+}
+
 // ---------------------------------------------------------------- GroupNorm
 // pass 1: per (batch, pixel-chunk) partial sum / sum-of-squares for every group.
 // Block = (C/8) x rows threads: a thread always owns the same 8-channel chunk, which touches
@@ -32,7 +56,20 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int ldx, float* __res
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
   const int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
   const f16* base = x + (size_t)b * HW * ldx + c0;
-  for (int p = p0 + prow; p < p1; p += rows) {
+  int p = p0 + prow;
+  for (; p + 3 * rows < p1; p += 4 * rows) {  // four pixels per trip, loads first: one memory round trip instead of four
+    f16x8 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const f16x8*)(base + (size_t)(p + u * rows) * ldx);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)v[u][e];
+        if (e < split) { s0 += f; q0 += f * f; } else { s1 += f; q1 += f * f; }
+      }
+  }
+  for (; p < p1; p += rows) {
     const f16x8 v = *(const f16x8*)(base + (size_t)p * ldx);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -82,12 +119,8 @@ __global__ void gn_stats_reduce_kernel(const float* __restrict__ part, int split
   if (bias) { bv0 = *(const f32x4*)(bias + c0); bv1 = *(const f32x4*)(bias + c0 + 4); }
   for (int p = p0 + prow; p < p1; p += rows) {
     const size_t row = (size_t)b * HW + p;
-    const float* pp = part + row * ldp + c0;
-    f32x4 a0 = *(const f32x4*)pp, a1 = *(const f32x4*)(pp + 4);
-    for (int z = 1; z < splits; ++z) {
-      const f32x4 t0 = *(const f32x4*)(pp + (size_t)z * slab), t1 = *(const f32x4*)(pp + (size_t)z * slab + 4);
-      a0 += t0; a1 += t1;
-    }
+    f32x4 a0, a1;
+    slab_sum8(part + row * ldp + c0, splits, slab, a0, a1);
     a0 += bv0; a1 += bv1;
     if (R) {
       const f16x8 r = *(const f16x8*)(R + row * ldr + c0);
@@ -136,10 +169,8 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const f16* __restrict__ 
   {
     const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
     float s = 0.f, q = 0.f;
-    if (g < groups) {
-      const float* p = partial + (size_t)b * nchunk * groups * 2 + g * 2;
-      for (int c = j; c < nchunk; c += 8) { s += p[(size_t)c * groups * 2]; q += p[(size_t)c * groups * 2 + 1]; }
-    }
+    if (g < groups)  // chunks j, j + 8, ... in order, loads up front (common.h)
+      sum_pairs_strided(partial + ((size_t)b * nchunk + j) * groups * 2 + g * 2, (size_t)8 * groups * 2, (nchunk - j + 7) / 8, s, q);
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
     if (g < groups && j == 0) {
@@ -297,12 +328,8 @@ __global__ __launch_bounds__(1024) void gn_reduce_fused_kernel(const float* __re
     if (i < total) {
       const int pix = i / nchs, c0 = (i - pix * nchs) * 8;
       const size_t row = (size_t)b * HW + pix;
-      const float* pp = part + row * ldp + cs + c0;
-      f32x4 a0 = *(const f32x4*)pp, a1 = *(const f32x4*)(pp + 4);
-      for (int z = 1; z < splits; ++z) {
-        const f32x4 t0 = *(const f32x4*)(pp + (size_t)z * slab), t1 = *(const f32x4*)(pp + (size_t)z * slab + 4);
-        a0 += t0; a1 += t1;
-      }
+      f32x4 a0, a1;
+      slab_sum8(part + row * ldp + cs + c0, splits, slab, a0, a1);
       if (bias) {
         const f32x4 b0 = *(const f32x4*)(bias + cs + c0), b1 = *(const f32x4*)(bias + cs + c0 + 4);
         a0 += b0; a1 += b1;
@@ -369,6 +396,72 @@ __global__ __launch_bounds__(1024) void gn_reduce_fused_kernel(const float* __re
       }
       *(f16x8*)(y + ((size_t)b * HW + pix) * ldy + cs + c0) = o;
     }
+  }
+}
+
+// GroupNorm WITHOUT an activation folded into the Linear / 1x1 conv that consumes it (the transformer's norm -> proj_in): per sample
+// b the normalisation is an affine map of the channels, y[c] = x[c] * a_b[c] + d_b[c] with a_b[c] = gamma[c] * rstd[b][g(c)] and
+// d_b[c] = beta[c] - mean[b][g(c)] * a_b[c], so   W (GN(x)) + bias = (W diag(a_b)) x + (bias + W d_b):  the GEMM runs on the RAW tensor
+// with per-sample weights (a grouped problem), and this kernel -- a few hundred KB per sample -- replaces the apply pass over the
+// whole tensor (one read + one write of it, and the normalised tensor itself).  Block = (8 output rows, sample): finalises the
+// sample's group statistics from the per-chunk partial sums of the statistics pass (fixed order), builds a_b / d_b in LDS, scales
+// its rows and reduces their bias terms in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void gn_fold_weights_kernel(const f16* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ partial, int nchunk, int C, int cpg, int groups,
+                                                              float inv_count, float eps, int Nout, f16* __restrict__ Wout, long long w_bs,
+                                                              float* __restrict__ bias_out, int bias_bs) {
+  __shared__ float st[64 * 2];
+  __shared__ float ad[2][2048];
+  __shared__ float red[256];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  {
+    const int g = tid >> 3, j = tid & 7;
+    float s = 0.f, q = 0.f;
+    if (g < groups)  // chunks j, j + 8, ... in order, loads up front (common.h)
+      sum_pairs_strided(partial + ((size_t)b * nchunk + j) * groups * 2 + g * 2, (size_t)8 * groups * 2, (nchunk - j + 7) / 8, s, q);
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (g < groups && j == 0) {
+      const float mean = s * inv_count;
+      st[g * 2] = mean;
+      st[g * 2 + 1] = rsqrtf(fmaxf(q * inv_count - mean * mean, 0.f) + eps);
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    const float a = gamma[c] * st[g * 2 + 1];
+    ad[0][c] = a;
+    ad[1][c] = beta[c] - st[g * 2] * a;
+  }
+  __syncthreads();
+  const int nch = C >> 3, rpp = 256 / nch;  // 8-channel chunks per row; rows per pass
+  const int cc = tid % nch, rr = tid / nch;
+  f16* Wb = Wout + (size_t)b * w_bs;
+  for (int r0 = 0; r0 < 8; r0 += rpp) {
+    const int n = blockIdx.x * 8 + r0 + rr;
+    const bool act = rr < rpp && r0 + rr < 8 && n < Nout;
+    float acc = 0.f;
+    if (act) {
+      const f16x8 w = *(const f16x8*)(W + (size_t)n * ldw + cc * 8);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float wf = (float)w[e];
+        o[e] = (f16)(wf * ad[0][cc * 8 + e]);
+        acc += wf * ad[1][cc * 8 + e];
+      }
+      *(f16x8*)(Wb + (size_t)n * ldw + cc * 8) = o;
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (act && cc == 0) {
+      float t = 0.f;
+      for (int k = 0; k < nch; ++k) t += red[rr * nch + k];
+      bias_out[(size_t)b * bias_bs + n] = (bias ? bias[n] : 0.f) + t;
+    }
+    __syncthreads();
   }
 }
 
@@ -451,9 +544,6 @@ size_t dtp_groupnorm_ws_bytes(int B, int HW, int C, int groups) {
 }
 
 // the two-launch GroupNorm; with `rd` the statistics pass also sums the producing conv's split-K slabs and writes x
-struct GnReduceSrc {
-  const float* part; int splits; long long slab; int ldp; const float* bias; const f16* R; int ldr;
-};
 static int groupnorm_two_pass(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, float* ws, int B, int HW, int C,
                               int groups, float eps, int silu, const GnReduceSrc* rd, hipStream_t s);
 
@@ -512,6 +602,39 @@ static int groupnorm_two_pass(const f16* x, int ldx, f16* y, int ldy, const floa
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
+// statistics pass alone (partial sums -> ws), optionally with the producing conv's split-K reduce folded in (rd): first half of
+// GroupNorm-folded-into-its-Linear (gn_fold_weights_kernel)
+int dtp_launch_groupnorm_stats(const f16* x, int ldx, float* ws, int B, int HW, int C, int groups, const GnReduceSrc* rd, hipStream_t s) {
+  if ((C & 7) || (C % groups) || (ldx & 7) || groups > 32 || C / groups < 4 || (C / groups < 8 && C / groups != 4) || (rd && (rd->ldp & 3))) {
+    dtp_set_error("groupnorm stats: C=%d groups=%d ldx=%d unsupported", C, groups, ldx);
+    return DTP_ERR_ARG;
+  }
+  const int cpg = C / groups, nch = C / 8, nchunk = gn_chunks(HW), ppc = (HW + nchunk - 1) / nchunk;
+  int rows = 1024 / nch;
+  if (rows > ppc) rows = ppc;
+  if (rows < 1) rows = 1;
+  const int threads = nch * rows;
+  if (threads > 1024) { dtp_set_error("groupnorm: C too large"); return DTP_ERR_ARG; }
+  if (rd)
+    hipLaunchKernelGGL(gn_stats_reduce_kernel, dim3(nchunk, B), dim3(threads), 0, s, rd->part, rd->splits, rd->slab, rd->ldp, rd->bias, rd->R, rd->ldr,
+                       (f16*)x, ldx, ws, HW, C, cpg, groups, ppc);
+  else
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(threads), 0, s, x, ldx, ws, HW, C, cpg, groups, ppc);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
+
+// second half: per-sample weights W diag(a_b) and biases bias + W d_b from the partial sums `ws` of dtp_launch_groupnorm_stats
+int dtp_launch_gn_fold_weights(const f16* W, int ldw, const float* bias, const float* gamma, const float* beta, const float* ws, int B, int HW,
+                               int C, int Nout, int groups, float eps, f16* Wout, long long w_bs, float* bias_out, int bias_bs, hipStream_t s) {
+  if ((C & 7) || C > 2048 || (C % groups) || groups > 32 || (ldw & 7) || C / 8 > 256) {
+    dtp_set_error("gn fold: C=%d groups=%d ldw=%d unsupported", C, groups, ldw);
+    return DTP_ERR_ARG;
+  }
+  hipLaunchKernelGGL(gn_fold_weights_kernel, dim3((Nout + 7) / 8, B), dim3(256), 0, s, W, ldw, bias, gamma, beta, ws, gn_chunks(HW), C, C / groups, groups,
+                     1.0f / ((float)HW * (C / groups)), eps, Nout, Wout, w_bs, bias_out, bias_bs);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
+
 // Can the split-K reduce of a [B*HW][C] conv output be folded into the GroupNorm that consumes it?  (single-launch GroupNorm
 // shapes only; at most 4 items of 8 channels per thread)
 bool dtp_reduce_groupnorm_supported(int HW, int C, int groups) {
@@ -522,7 +645,7 @@ bool dtp_reduce_groupnorm_supported(int HW, int C, int groups) {
   while ((G * cpg) & 7) G *= 2;
   if (G > 4 || groups % G) return false;
   const int items = HW * ((G * cpg) >> 3);
-  const int blk = items >= 2048 ? 1024 : (items >= 512 ? 512 : 256);
+  const int blk = items >= 1024 ? 1024 : (items >= 512 ? 512 : 256);  // reduce kernel: as many waves as items allow (latency-bound slab reads)
   return (items + blk - 1) / blk <= 4;
 }
 
@@ -545,7 +668,7 @@ int dtp_launch_reduce_groupnorm(const float* part, int splits, long long slab, i
   const float inv = 1.0f / ((float)HW * cpg);
   dim3 grid(groups / G, B);
   const int items = HW * ((G * cpg) >> 3);
-  const dim3 blk(items >= 2048 ? 1024 : (items >= 512 ? 512 : 256));
+  const dim3 blk(items >= 1024 ? 1024 : (items >= 512 ? 512 : 256));
 #define DTP_RGN(GG) hipLaunchKernelGGL((gn_reduce_fused_kernel<GG, 4>), grid, blk, 0, s, part, splits, slab, ldp, bias, R, ldr, c_out, ldc, y, ldy, gamma, beta, HW, cpg, silu, inv, eps)
   if (G == 1) DTP_RGN(1); else if (G == 2) DTP_RGN(2); else DTP_RGN(4);
 #undef DTP_RGN

@@ -186,12 +186,16 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
   const int dB = dup ? dup->B : 0;
   const int C = x.C, S = x.H * x.W, N = x.B + dB;  // x holds the samples that are really evaluated up to the cross-attention
   T t, y, n1, qkv, a, y2, n2, y3, n3, f;
-  RC(b.gn(x, w.gn, 1e-6f, false, t));
   // LayerNorms are folded into their consumer GEMMs; the row statistics ride on the producer's epilogue
   RowStats st1, st2, st3;
   RC(b.alloc_stats(x.rows(), C, st1));
-  RC(b.linear(t, w.proj_in, nullptr, 0, y, &st1));
-  b.release(t);
+  if (b.gn_linear_supported(x, w.proj_in)) {  // levels 0-1: the GroupNorm becomes per-sample proj_in weights (Builder::gn_linear)
+    RC(b.gn_linear(x, w.gn, 1e-6f, w.proj_in, y, &st1));
+  } else {
+    RC(b.gn(x, w.gn, 1e-6f, false, t));
+    RC(b.linear(t, w.proj_in, nullptr, 0, y, &st1));
+    b.release(t);
+  }
   RC(b.linear(y, w.qkv, nullptr, 0, qkv, nullptr, &st1));  // LN1 folded
   b.release_stats(st1);
   T q = qkv, k = qkv, v = qkv;

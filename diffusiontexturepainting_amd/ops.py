@@ -164,6 +164,19 @@ def reduce_groupnorm(part, gamma, beta, bias=None, resid=None, groups=32, eps=1e
     return out, y
 
 
+def gn_fold_weights(x, wp, n_out, bias, gamma, beta, groups=32, eps=1e-6):
+    """x f16 [B,HW,C], wp packed f16 [rows, ldw] -> (per-sample packed weights f16 [B, rows, ldw], biases f32 [B, rows]) such that
+    proj(GroupNorm(x_b)) == x_b @ W_b^T + b_b (GroupNorm without activation folded into its consumer)."""
+    lib = _lib.load()
+    b, hw, c = x.shape
+    rows = _up(n_out, 128)
+    wout = torch.zeros(b, rows, wp.shape[1], dtype=torch.float16, device=x.device)
+    bout = torch.zeros(b, rows, dtype=torch.float32, device=x.device)
+    check(lib.dtp_op_gn_fold_weights(ptr(x), ptr(wp), wp.shape[1], ptr(bias), ptr(gamma), ptr(beta), b, hw, c, n_out, groups, eps, ptr(wout), ptr(bout),
+                                     _stream()), "gn_fold_weights")
+    return wout, bout
+
+
 def layernorm(x, gamma, beta, eps=1e-5):
     lib = _lib.load()
     c = x.shape[-1]

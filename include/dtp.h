@@ -211,6 +211,11 @@ int dtp_op_measure_peaks(double* mfma_f16_tflops, double* hbm_copy_gbs);
  * behind a conv); one launch for HW <= 256, reduce-in-statistics + apply above */
 int dtp_op_reduce_groupnorm(const float* part, int splits, const float* bias, const void* resid, void* conv_out, void* y, const float* gamma,
                             const float* beta, int B, int HW, int C, int groups, float eps, int silu, dtp_stream s);
+/* GroupNorm (no activation) folded into the Linear / 1x1 conv that consumes it (Transformer2DModel: norm -> proj_in): from x f16
+ * [B][HW][C] and the packed weights W f16 [rows][ldw] (+ bias[Nout]) compute per-sample Wout f16 [B][rows][ldw] = W diag(gamma * rstd_b)
+ * and bias_out f32 [B][rows] = bias + W (beta - mean_b * rstd_b * gamma), rows = roundup(Nout, 128): proj(GN(x_b)) == Wout_b x_b + bias_out_b */
+int dtp_op_gn_fold_weights(const void* x, const void* W, int ldw, const float* bias, const float* gamma, const float* beta, int B, int HW, int C,
+                           int Nout, int groups, float eps, void* Wout, float* bias_out, dtp_stream s);
 int dtp_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int rows, int C,
                      float eps, dtp_stream s);
 int dtp_op_attention(const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo, int B, int H,

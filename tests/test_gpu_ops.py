@@ -344,6 +344,24 @@ def test_reduce_groupnorm(ops, b, hw, c, splits, silu, bias, resid):
     close(y, ref)
 
 
+@pytest.mark.parametrize("b,hw,c,n", [(3, 4096, 320, 320), (2, 1024, 640, 640), (1, 1024, 1280, 1280), (2, 1600, 960, 320)])
+def test_groupnorm_folded_into_linear(ops, b, hw, c, n):
+    """proj_in(GroupNorm(x)) as a grouped GEMM on the RAW x with per-sample weights W diag(gamma rstd_b) and biases b + W (beta - mean_b
+    rstd_b gamma): statistics pass + fold kernel + the grouped GEMM against torch (x carries a per-channel offset: the fold has to
+    cancel the group means through the bias term)."""
+    from diffusiontexturepainting_amd._lib import GF_BIAS
+    g = torch.Generator().manual_seed(47)
+    x = (rnd(b, hw, c, seed=48).float() * 1.5 + 0.8 * torch.randn(c, generator=g)).half()
+    w = rnd(n, c, seed=49, scale=c ** -0.5).float()
+    bias = 0.1 * torch.randn(n, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    ref = F.linear(F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, 1e-6).permute(0, 2, 1), w, bias)
+    wp = ops.pack_linear(w.cuda())
+    wf, bf = ops.gn_fold_weights(x.cuda(), wp, n, bias.cuda(), gamma.cuda(), beta.cuda())
+    got = ops.gemm(x.cuda().view(b * hw, c), wf.view(-1, wf.shape[-1]), n, c, bias=bf.view(-1), flags=GF_BIAS, batch=b)
+    close(got.view(b, hw, n), ref, tol=4e-3)
+
+
 @pytest.mark.parametrize("rows,c", [(1000, 320), (333, 640), (64, 1280), (14, 768), (5, 2048)])
 def test_layernorm(ops, rows, c):
     x = rnd(rows, c, seed=50) * 1.5 + 0.3
