@@ -2,6 +2,7 @@
 // NHWC fp16 tensors, 16-byte (8 x f16) vector accesses, fp32 statistics, wave64 shuffles.
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -105,12 +106,15 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int ldx, float* __res
 // + gn_stats_kernel.
 __global__ void gn_stats_reduce_kernel(const float* __restrict__ part, int splits, long long slab, int ldp, const float* __restrict__ bias,
                                        const f16* __restrict__ R, int ldr, f16* __restrict__ c_out, int ldc, float* __restrict__ partial,
-                                       int HW, int C, int cpg, int groups, int pix_per_chunk) {
+                                       int HW, int cs_ch, int cpg, int groups, int pix_per_chunk) {
+  // blockIdx = (pixel chunk, sample, channel slab of cs_ch channels: whole groups and whole 16-byte chunks).  Large maps use one
+  // slab (all channels); small maps (HW <= 256) are cut along the channels as well so that every CU pulls slab data (the
+  // single-launch gn_reduce_fused_kernel has one block per (sample, group slab): 96 blocks at per-CU fetch speed)
   __shared__ float red[1024 * 4];
-  const int nch = C >> 3;
+  const int nch = cs_ch >> 3, cbase = blockIdx.z * cs_ch;
   const int cc = threadIdx.x % nch, prow = threadIdx.x / nch, rows = blockDim.x / nch;
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-  const int c0 = cc * 8;
+  const int c0 = cbase + cc * 8;
   const int g0 = c0 / cpg;
   const int split = min(8, (g0 + 1) * cpg - c0);
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
@@ -143,11 +147,13 @@ __global__ void gn_stats_reduce_kernel(const float* __restrict__ part, int split
   red[threadIdx.x * 4 + 3] = q1;
   __syncthreads();
   float* out = partial + ((size_t)b * nchunk + chunk) * groups * 2;
-  for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+  const int gfirst = cbase / cpg, gcount = cs_ch / cpg;
+  for (int gi = threadIdx.x; gi < gcount; gi += blockDim.x) {
+    const int g = gfirst + gi;
     float s = 0.f, q = 0.f;
-    const int cfirst = (g * cpg) >> 3, clast = ((g + 1) * cpg - 1) >> 3;
+    const int cfirst = (g * cpg - cbase) >> 3, clast = ((g + 1) * cpg - 1 - cbase) >> 3;
     for (int c = cfirst; c <= clast; ++c) {
-      const int sel = ((c * 8) / cpg == g) ? 0 : 2;
+      const int sel = ((cbase + c * 8) / cpg == g) ? 0 : 2;
       for (int r = 0; r < rows; ++r) {
         s += red[(r * nch + c) * 4 + sel];
         q += red[(r * nch + c) * 4 + sel + 1];
@@ -532,6 +538,15 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* __restrict
 
 }  // namespace
 
+// statistics-with-reduce pass: pixel chunks and the channel slab of a block (see gn_stats_reduce_kernel)
+static int gn_chunks_reduce(int HW) { return HW >= 1024 ? (HW / 64 > 128 ? 128 : HW / 64) : (HW >= 32 ? HW / 32 : 1); }
+static int gn_slab_channels(int HW, int C, int cpg) {
+  if (HW >= 1024) return C;
+  int cs = cpg;
+  while (cs & 7) cs += cpg;  // lcm(8, cpg): whole groups, whole 16-byte chunks
+  return (C % cs) == 0 ? cs : C;
+}
+
 static int gn_chunks(int HW) {  // pixel chunks per batch item for the statistics pass (more chunks = more loads in flight)
   int n = HW / 64;
   if (n < 1) n = 1;
@@ -540,7 +555,7 @@ static int gn_chunks(int HW) {  // pixel chunks per batch item for the statistic
 }
 
 size_t dtp_groupnorm_ws_bytes(int B, int HW, int C, int groups) {
-  return (size_t)B * gn_chunks(HW) * groups * 2 * sizeof(float);
+  return (size_t)B * std::max(gn_chunks(HW), gn_chunks_reduce(HW)) * groups * 2 * sizeof(float);
 }
 
 // the two-launch GroupNorm; with `rd` the statistics pass also sums the producing conv's split-K slabs and writes x
@@ -575,8 +590,9 @@ int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* ga
 static int groupnorm_two_pass(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, float* ws, int B, int HW, int C,
                               int groups, float eps, int silu, const GnReduceSrc* rd, hipStream_t s) {
   const int cpg = C / groups;
-  const int nch = C / 8;
-  const int nchunk = gn_chunks(HW);
+  const int cs = rd ? gn_slab_channels(HW, C, cpg) : C;       // channels per block of the statistics pass
+  const int nch = cs / 8;
+  const int nchunk = rd ? gn_chunks_reduce(HW) : gn_chunks(HW);
   const int ppc = (HW + nchunk - 1) / nchunk;
   // few, fat blocks: up to 1024 threads so that many 16-byte loads are in flight per block while the number of
   // partial sums the apply kernel has to re-reduce stays small
@@ -586,11 +602,11 @@ static int groupnorm_two_pass(const f16* x, int ldx, f16* y, int ldy, const floa
   const int threads = nch * rows;
   if (threads > 1024) { dtp_set_error("groupnorm: C too large"); return DTP_ERR_ARG; }
   if (rd)
-    hipLaunchKernelGGL(gn_stats_reduce_kernel, dim3(nchunk, B), dim3(threads), 0, s, rd->part, rd->splits, rd->slab, rd->ldp, rd->bias, rd->R, rd->ldr,
-                       (f16*)x, ldx, ws, HW, C, cpg, groups, ppc);
+    hipLaunchKernelGGL(gn_stats_reduce_kernel, dim3(nchunk, B, C / cs), dim3(threads), 0, s, rd->part, rd->splits, rd->slab, rd->ldp, rd->bias, rd->R,
+                       rd->ldr, (f16*)x, ldx, ws, HW, cs, cpg, groups, ppc);
   else
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(threads), 0, s, x, ldx, ws, HW, C, cpg, groups, ppc);
-  const long long per_batch = (long long)HW * nch;
+  const long long per_batch = (long long)HW * (C / 8);
   // one fat block per CU (tools/diag_gn.py sweep: 1024 threads x <= 256 blocks is 5-7 % ahead of 256 x 768): every block
   // re-reduces the partials of its batch item first, so fewer blocks re-read them less often
   const int at = 1024;
@@ -609,6 +625,7 @@ int dtp_launch_groupnorm_stats(const f16* x, int ldx, float* ws, int B, int HW, 
     dtp_set_error("groupnorm stats: C=%d groups=%d ldx=%d unsupported", C, groups, ldx);
     return DTP_ERR_ARG;
   }
+  // the consumer (gn_fold_weights_kernel) reads gn_chunks(HW) partials per sample: keep the plain chunking and whole-C blocks here
   const int cpg = C / groups, nch = C / 8, nchunk = gn_chunks(HW), ppc = (HW + nchunk - 1) / nchunk;
   int rows = 1024 / nch;
   if (rows > ppc) rows = ppc;
@@ -616,7 +633,7 @@ int dtp_launch_groupnorm_stats(const f16* x, int ldx, float* ws, int B, int HW, 
   const int threads = nch * rows;
   if (threads > 1024) { dtp_set_error("groupnorm: C too large"); return DTP_ERR_ARG; }
   if (rd)
-    hipLaunchKernelGGL(gn_stats_reduce_kernel, dim3(nchunk, B), dim3(threads), 0, s, rd->part, rd->splits, rd->slab, rd->ldp, rd->bias, rd->R, rd->ldr,
+    hipLaunchKernelGGL(gn_stats_reduce_kernel, dim3(nchunk, B, 1), dim3(threads), 0, s, rd->part, rd->splits, rd->slab, rd->ldp, rd->bias, rd->R, rd->ldr,
                        (f16*)x, ldx, ws, HW, C, cpg, groups, ppc);
   else
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(threads), 0, s, x, ldx, ws, HW, C, cpg, groups, ppc);
@@ -657,7 +674,12 @@ int dtp_launch_reduce_groupnorm(const float* part, int splits, long long slab, i
     dtp_set_error("reduce+groupnorm: HW=%d C=%d groups=%d unsupported", HW, C, groups);
     return DTP_ERR_ARG;
   }
-  if (!dtp_reduce_groupnorm_supported(HW, C, groups)) {  // large maps: reduce folded into the statistics pass, then the apply pass
+  // small maps: the single launch has one block per (sample, group slab) -- 96 blocks pulling 8-16 slabs at per-CU fetch speed
+  // (18 us at HW = 256, C = 1280, 8 slabs).  The two-pass form cuts the statistics pass along pixels AND channels (768 blocks), but
+  // its second launch costs more than the parallelism returns: 124.9 vs 122.3 ms per stamp on the same box (+456 graph nodes at
+  // ~5.5 us each) -- kept behind $DTP_GN_SMALL_TWOPASS=1 as the measured alternative.
+  static const bool small_fused = [] { const char* e = getenv("DTP_GN_SMALL_TWOPASS"); return !(e && e[0] && e[0] != '0'); }();
+  if (!dtp_reduce_groupnorm_supported(HW, C, groups) || (!small_fused && stats_ws && HW >= 32)) {  // reduce folded into the statistics pass, then the apply pass
     if (!stats_ws) { dtp_set_error("reduce+groupnorm: the two-pass form needs the statistics workspace"); return DTP_ERR_ARG; }
     const GnReduceSrc rd = {part, splits, slab, ldp, bias, R, ldr};
     return groupnorm_two_pass(c_out, ldc, y, ldy, gamma, beta, stats_ws, B, HW, C, groups, eps, silu, &rd, s);
