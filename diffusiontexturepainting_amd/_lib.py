@@ -31,7 +31,8 @@ PROF_KINDS = [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 
      "conv_halo_kernel<8, 8, 128>", "gemm_kernel<256, 128, 2>", "gemm_kernel<256, 128, 3>", "gemm_kernel<128, 256, 2>",
      "gemm_kernel<128, 256, 3>", "gemm_wide_kernel<256, 256>", "gemm_wide_kernel<256, 320>", "gemm_fp8_kernel"] + \
     [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 4}, 2>" for i in range(8)] + \
-    [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, 3, 1, {(4, 8)[i // 4]}>" for i in range(8)]
+    [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, 3, 1, {(4, 8)[i // 4]}>" for i in range(8)] + \
+    ["xattn_kernel (cross-attention GEMM pair)"]
 
 
 class GemmDesc(C.Structure):
@@ -89,6 +90,7 @@ SYMBOLS = {
     "dtp_op_groupnorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "dtp_op_measure_peaks": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dtp_op_reduce_groupnorm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "dtp_op_xattn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "dtp_op_gn_fold_weights": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "dtp_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
     "dtp_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp]),

@@ -78,6 +78,7 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
   p.batch = d->batch; p.a_bs = d->a_bs; p.w_bs = d->w_bs; p.c_bs = d->c_bs; p.r_bs = d->r_bs;
   p.bias_bs = d->bias_bs; p.lns_bs = d->lns_bs; p.sm_valid = d->sm_valid;
   p.st_out = d->st_out; p.st_in = d->st_in; p.st_parts = d->st_parts;
+  if (p.batch > 1) p.st_rows = p.batch * p.M;  // statistics tables are [parts][batch * M][2]
   p.W8 = (const unsigned char*)d->W8; p.ldw8 = d->ldw8; p.a_scale = d->a_scale; p.w_scale = d->w_scale;
   static bool fp8_init = false;
   if (!fp8_init) { dtp_gemm_fp8_init(); fp8_init = true; }
@@ -186,6 +187,21 @@ int dtp_op_gn_fold_weights(const void* x, const void* W, int ldw, const float* b
   const int rows = (Nout + 127) / 128 * 128;
   return dtp_launch_gn_fold_weights((const f16*)W, ldw, bias, gamma, beta, g_ops.ws, B, HW, C, Nout, groups, eps, (f16*)Wout, (long long)rows * ldw, bias_out,
                                     rows, (hipStream_t)s);
+}
+
+int dtp_op_xattn(const void* X, const void* W1, const float* b1, const float* lns1, const float* st_in, int st_parts, const void* W2, const float* b2,
+                 const void* R, void* Y, float* st_out, int S, int C, int N, int sm_valid, float ln_eps, dtp_stream s) {
+  std::lock_guard<std::mutex> lk(g_ops_mu);
+  int rc = ops_init();
+  if (rc) return rc;
+  static bool init = false;
+  if (!init) { dtp_xattn_init(); init = true; }
+  XattnParams p = {};
+  p.X = (const f16*)X; p.ldx = C; p.W1 = (const f16*)W1; p.w1_bs = (long long)128 * C; p.b1 = b1; p.lns1 = lns1;
+  p.st_in = st_in; p.st_parts = st_parts; p.st_rows = N * S; p.ln_eps = ln_eps;
+  p.W2 = (const f16*)W2; p.w2_bs = (long long)((C + 127) / 128 * 128) * 128; p.b2 = b2; p.R = (const f16*)R; p.ldr = C;
+  p.Y = (f16*)Y; p.ldy = C; p.st_out = st_out; p.S = S; p.C = C; p.N = N; p.sm_valid = sm_valid; p.zero = (const f16*)g_ops.zero;
+  return dtp_launch_xattn(p, (hipStream_t)s);
 }
 
 int dtp_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int rows, int C,

@@ -118,6 +118,8 @@ enum {
   GF_SOFTMAX16 = 4096,// epilogue: softmax over each aligned group of 16 output columns (first sm_valid of them; the rest -> 0)
   GF_MFAST = 1 << 20,// internal: tile_m varies fastest (neighbouring workgroups share the W panel)
   GF_NOREDUCE = 1 << 21,// internal: a split launch leaves its fp32 slabs for the consumer (fused reduce + GroupNorm)
+  GF_GNAPPLY = 1 << 22, // conv_halo_kernel only: A is the RAW pre-GroupNorm tensor; the staged input patch is normalised (+ SiLU) in LDS
+                        // from the statistics partials gn_part (GemmParams::gn_*): no apply launch, no normalised tensor
 };
 
 struct GemmParams {
@@ -150,6 +152,11 @@ struct GemmParams {
   long long a_bs, w_bs, c_bs, r_bs;
   int bias_bs, lns_bs, st_rows;
   int sm_valid;      // GF_SOFTMAX16: valid columns per group of 16
+  // GF_GNAPPLY: GroupNorm of the conv input applied on the staged patch.  gn_part = per-chunk (sum, sumsq) partials of the statistics
+  // pass [B][gn_nchunk][groups][2] (groups = Cin / gn_cpg <= 32), gn_gamma / gn_beta fp32 [Cin]
+  const float *gn_part, *gn_gamma, *gn_beta;
+  int gn_nchunk, gn_cpg, gn_silu;
+  float gn_eps;
   // fp8 (e4m3) variant (gemm_fp8.hip, tile ids 24..27): W8 = per-tensor quantised copy of W, [N_pad][ldw8] bytes (K padded to 128)
   const unsigned char* W8;
   int ldw8;
@@ -168,6 +175,7 @@ void dtp_gemm_pick(GemmParams& p, int* tile, int num_cu);  // sets splits/kb_per
 int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, float* stats_ws,
                          int B, int HW, int C, int groups, float eps, int silu, hipStream_t s);
 size_t dtp_groupnorm_ws_bytes(int B, int HW, int C, int groups);
+int dtp_groupnorm_stat_chunks(int HW);  // pixel chunks per sample of dtp_launch_groupnorm_stats (partials [B][chunks][groups][2])
 // split-K reduce (+ bias, + residual) of a conv output fused with the GroupNorm (+SiLU) that consumes it: writes the fp16 conv
 // output c_out AND the normalised tensor y -- in one launch where dtp_reduce_groupnorm_supported() (HW <= 256), otherwise the
 // reduce rides in the statistics pass of the two-launch GroupNorm (needs stats_ws, dtp_groupnorm_ws_bytes)
@@ -201,6 +209,25 @@ struct AttnParams {
 int dtp_launch_attention(const AttnParams& p, hipStream_t s);
 // attention_fp8.hip: the same contraction on the fp8 (e4m3) MX MFMA; q_scale / v_scale = per-tensor scales (powers of two)
 int dtp_launch_attention_fp8(const AttnParams& p, float q_scale, float v_scale, hipStream_t s);
+
+// ---------------------------------------------------------------- fused cross-attention GEMM pair (xattn.hip)
+// Y = softmax_16(LN(X) W1^T + b1) W2^T + b2 + R per sample, X / R / Y [N*S][C] fp16; see xattn.hip
+struct XattnParams {
+  const f16* X; int ldx;             // LayerNorm input (raw), rows smp*S + m
+  const f16* W1; long long w1_bs;    // per sample [128][C] (LayerNorm gamma folded in), K contiguous
+  const float *b1, *lns1;            // per sample [128]: bias (+ W.beta), row sums of W1
+  const float* st_in; int st_parts, st_rows; float ln_eps;  // producer's per-row (sum, sumsq) partials [parts][st_rows][2]
+  const f16* W2; long long w2_bs;    // per sample [roundup(C,128)][128]
+  const float* b2;                   // [C] (shared) or null
+  const f16* R; int ldr;             // residual rows
+  f16* Y; int ldy;
+  float* st_out;                     // [ceil(C/128)][st_rows][2] partials of the stored rows, or null
+  int S, C, N, sm_valid;             // rows per sample, channels, samples, valid columns per 16-group
+  const f16* zero;                   // >= 16 bytes of zeros
+};
+bool dtp_xattn_supported(const XattnParams& p);
+int dtp_launch_xattn(const XattnParams& p, hipStream_t s);
+void dtp_xattn_init();
 
 // ---------------------------------------------------------------- elementwise / layout (elementwise.hip)
 int dtp_launch_concat_channels(const f16* a, int lda, int Ca, const f16* b, int ldb, int Cb, f16* y, int ldy, long long rows,

@@ -33,7 +33,12 @@ __device__ __forceinline__ int halo_key(int hy, int hx) {
   else return ((hy * (TW + 2) + hx) >> 1) & 7;
 }
 
-template <int TH, int TW, int BN>
+// GN: the input is the RAW pre-GroupNorm tensor (GF_GNAPPLY).  Every workgroup finalises its image's group statistics from the
+// partial sums of the statistics pass and builds the per-channel (scale, shift) table in LDS while its first DMA is in flight; each
+// time a halo block has landed, every thread normalises (+ SiLU) exactly the 16-byte chunks it DMA'd itself -- in place, before the
+// barrier that publishes the block -- so the nine taps read the normalised patch.  Pixels outside the image keep their zeros (the
+// padding applies to the normalised tensor).  One launch and one read + write of the whole tensor fewer per GroupNorm -> conv pair.
+template <int TH, int TW, int BN, bool GN = false>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
   constexpr int BM = TH * TW;                       // output pixels per workgroup (64 or 128)
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -76,11 +81,13 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
   // halo blocks: row = halo pixel; shortcut blocks: row = tile row.
   const int kc8 = lane & 7;
   const f16 *hsrc[HL], *tsrc[HL];
+  int hkc[HL];  // GN: channel offset (inside the 64-channel block) of the chunk this thread stages with piece i
 #pragma unroll
   for (int i = 0; i < HL; ++i) {
     const int hp = (i * 4 + wave) * 8 + (lane >> 3);
     const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
     const int kc = ((kc8 ^ halo_key<TW>(hy, hx)) << 3);
+    hkc[i] = kc;
     const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
     const bool ok = (hp < HP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
     hsrc[i] = ok ? p.A + ((size_t)(img * H + iy) * W + ix) * p.lda + kc : nullptr;
@@ -135,6 +142,33 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
     issue_a(0, blk);
     issue_w(0, ita);
     if (nit > 1) issue_w(1, ita + 1);
+  }
+  float* const gn_tab = (float*)(smem + 2 * HBYTES + 3 * WBYTES);  // GN: [Cin][2] = (scale, shift) of this image's channels
+  if constexpr (GN) {
+    float* const gst = gn_tab + 2 * p.Cin;  // [32][2] mean, rstd
+    const int groups = p.Cin / p.gn_cpg;
+    {
+      const int g = tid >> 3, j = tid & 7;
+      float s = 0.f, q = 0.f;
+      if (g < groups)
+        sum_pairs_strided(p.gn_part + ((size_t)img * p.gn_nchunk + j) * groups * 2 + g * 2, (size_t)8 * groups * 2, (p.gn_nchunk - j + 7) / 8, s, q);
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+      if (g < groups && j == 0) {
+        const float inv = 1.0f / ((float)(H * W) * (float)p.gn_cpg);
+        const float mean = s * inv;
+        gst[2 * g] = mean;
+        gst[2 * g + 1] = rsqrtf(fmaxf(q * inv - mean * mean, 0.f) + p.gn_eps);
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < p.Cin; c += 256) {
+      const int g = c / p.gn_cpg;
+      const float a = p.gn_gamma[c] * gst[2 * g + 1];
+      gn_tab[2 * c] = a;
+      gn_tab[2 * c + 1] = p.gn_beta[c] - gst[2 * g] * a;
+    }
+    __syncthreads();
   }
   int wcur = 0, wnxt = 2, abuf = 0;
   bool changed = false, refilled_prev = false;
@@ -209,6 +243,31 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
       if (t + 1 >= nit) wait_vmcnt<0>();
       else if (refilled_prev && !changed) wait_vmcnt<WR + HL>();
       else wait_vmcnt<WR>();
+      if constexpr (GN) {
+        if ((t == 0 || changed) && blk < ncb) {  // a fresh halo block: this wave's pieces of it have landed (the wait above)
+          char* const hb = halo + abuf * HBYTES;
+          const bool silu = p.gn_silu != 0;
+#pragma unroll
+          for (int i = 0; i < HL; ++i) {
+            if (hsrc[i]) {  // pixels outside the image (and rows beyond the patch) stay zero
+              f16x8* const q = (f16x8*)(hb + ((i * 4 + wave) * 8) * 128 + lane * 16);
+              const f16x8 v = *q;
+              const float* tb = gn_tab + 2 * (blk * 64 + hkc[i]);
+              const f32x4 t0 = *(const f32x4*)tb, t1 = *(const f32x4*)(tb + 4), t2 = *(const f32x4*)(tb + 8), t3 = *(const f32x4*)(tb + 12);
+              const float ab[16] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3], t2[0], t2[1], t2[2], t2[3], t3[0], t3[1], t3[2], t3[3]};
+              f16x8 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float f = fmaf((float)v[e], ab[2 * e], ab[2 * e + 1]);
+                if (silu) f = f / (1.0f + __expf(-f));
+                o[e] = (f16)f;
+              }
+              *q = o;
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rewritten chunks are in LDS before the barrier publishes the block
+        }
+      }
       __builtin_amdgcn_s_barrier();
       // the first iteration of every block launches the DMA of the next block (if it is inside this split's range).
       // DMA pieces of this iteration -- the next block's halo first (the counted waits above rely on that order), then
@@ -320,12 +379,17 @@ constexpr int halo_lds() {
   return 2 * HL * 32 * 128 + 3 * BN * 128;
 }
 
+constexpr int GN_MAX_CIN = 1024;  // (scale, shift) table: 8 KB at most, so that the 8x16 x 64 variant still fits twice on a CU
+
 template <int TH, int TW, int BN>
 int launch_halo(const GemmParams& p, hipStream_t s) {
   const int H = p.Hi, W = p.Wi;
   const int blocks = (p.M / (H * W)) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * ((p.N + BN - 1) / BN);
   constexpr int lds = halo_lds<TH, TW, BN>();
-  hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN>), dim3(blocks, 1, p.splits), dim3(256), lds, s, p);
+  if (p.flags & GF_GNAPPLY)
+    hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, true>), dim3(blocks, 1, p.splits), dim3(256), lds + p.Cin * 8 + 256, s, p);
+  else
+    hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, false>), dim3(blocks, 1, p.splits), dim3(256), lds, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
@@ -334,7 +398,8 @@ int launch_halo(const GemmParams& p, hipStream_t s) {
 template <int TH, int TW, int BN>
 static void set_halo_attr() {
   constexpr int lds = halo_lds<TH, TW, BN>();
-  (void)hipFuncSetAttribute((const void*)conv_halo_kernel<TH, TW, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)conv_halo_kernel<TH, TW, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)conv_halo_kernel<TH, TW, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + GN_MAX_CIN * 8 + 256);
 }
 
 void dtp_conv_halo_init() {
@@ -347,6 +412,9 @@ void dtp_conv_halo_init() {
 // variant: 0 = 8x16 x 64, 1 = 8x16 x 128, 2 = 8x8 x 64, 3 = 8x8 x 128.  p.W must be the channel-block-major packing
 // ([cb][tap][64] then the fused-shortcut columns); p.kb_per_split / p.splits count 64-wide k-blocks like gemm_kernel.
 bool dtp_conv_halo_supported(const GemmParams& p) {
+  if ((p.flags & GF_GNAPPLY) && (!p.gn_part || !p.gn_gamma || !p.gn_beta || p.Cin > GN_MAX_CIN || p.gn_cpg < 1 || (p.Cin % p.gn_cpg) || p.Cin / p.gn_cpg > 32 ||
+                                 p.gn_nchunk < 1))
+    return false;
   return (p.flags & GF_CONV3) && !(p.flags & (GF_UPS2 | GF_GEGLU | GF_OUT_F32 | GF_LNFOLD | GF_ROWSTATS | GF_BIAS_M | GF_GELU | GF_QUICKGELU | GF_SILU)) &&
          p.stride == 1 && p.pad == 1 && (!p.A2 || ((p.Cin2 & 63) == 0 && (p.lda2 & 7) == 0)) && (p.Cin & 63) == 0 &&
          (p.N & 7) == 0 && p.Ho == p.Hi && p.Wo == p.Wi &&

@@ -50,7 +50,7 @@ struct Ctx;
 // A launch program: a flat list of closures bound to statically planned buffers.
 using Op = std::function<int(hipStream_t, int /*step*/)>;
 // profiling classes (dtp_profile_rows): 0-11 = gemm_kernel<BM,BN,NS> variants (id = shape + 4*(NS-2)), then the rest
-enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_BIG0 = 21, PK_WIDE0 = 25, PK_FP8 = 27, PK_KH2 = 28, PK_LW = 36, PK_COUNT = 44 };
+enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_BIG0 = 21, PK_WIDE0 = 25, PK_FP8 = 27, PK_KH2 = 28, PK_LW = 36, PK_XATTN = 44, PK_COUNT = 45 };
 struct ProfRec {
   int kind;
   double flops, bytes;
@@ -241,6 +241,9 @@ struct Ctx {
   int* finite_flag = nullptr;     // device: set to 1 by the post-loop finiteness check ("check_finite" option)
   bool check_finite = false;
   bool dedupe_prefix = true;      // uncond and cond branches share the UNet prefix up to the first cross-attention ($DTP_NO_DEDUPE=1: off, A/B)
+  bool fuse_gn_conv = false;      // GroupNorm + SiLU applied on the halo conv's staged input patch (GF_GNAPPLY).  OFF: measured +4.9 ms per
+                                  // stamp (the normalisation costs every workgroup ~40 % -- DESIGN.md 3.6); option "fuse_gn_conv" / $DTP_GN_CONV=1
+  bool fuse_xattn = true;         // the two grouped GEMMs of a cross-attention as one launch (xattn.hip; $DTP_NO_XATTN=1: off, A/B)
   bool fold_gn_linear = true;     // transformer GroupNorm folded into per-sample proj_in weights at HW >= 1024 ($DTP_NO_FOLD_GN=1: off, A/B)
   bool fuse_reduce_gn = true;     // fold a split-K conv's reduce into the GroupNorm that consumes it ($DTP_NO_FUSE_REDUCE_GN=1: off, A/B)
   bool fp8_linear = false;        // UNet transformer Linears / 1x1 convs on the fp8 MX MFMA (configs[4]); fixed once a UNet program exists
@@ -307,6 +310,9 @@ struct Builder {
   bool claim_reduce(const T& x, GemmParams& gp, int& bias_step_off);
   bool gn_linear_supported(const T& x, const ConvW& w) const;
   int gn_linear(const T& x, const NormW& n, float eps, const ConvW& w, T& y, RowStats* emit);
+  // GroupNorm + SiLU + 3x3 conv (stride 1, pad 1); the apply pass rides on the conv's staged input where the halo kernel can take it
+  int gn_conv3(const T& x, const NormW& n, float eps, const ConvW& w, const T* resid, int bias_step_off, T& y, const T* tail, const T* dst);
+  struct { bool active = false; const float *part = nullptr, *gamma = nullptr, *beta = nullptr; float eps = 0.f; int nchunk = 0, cpg = 0; } gn_fused;
   int ln(const T& x, const NormW& n, T& y);
   // conv3x3; bias_step_off >= 0 selects the per-step bias slice from the temb table instead of w.b
   int conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, int Ho, int Wo, const T* resid, int bias_step_off,

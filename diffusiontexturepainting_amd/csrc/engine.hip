@@ -482,6 +482,7 @@ static bool tune_entry_valid(const GemmParams& p, int tile, int sp) {
   if (sp < 1 || sp > p.nkb) return false;
   const bool halo = tile >= 12 && tile < 16;
   if (halo) return p.Wcb && dtp_conv_halo_supported(p) && p.batch <= 1;
+  if (p.flags & GF_GNAPPLY) return false;  // only the halo kernel normalises its staged input
   int bm = 0, bn = 0, ns = 0;
   if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) return false;
   if (tile >= 24 && tile < 32) { GemmParams q = p; q.splits = 1; return sp == 1 && tile <= 28 && dtp_gemm_fp8_supported(q) && !((p.flags & GF_GEGLU) && (bn % 128)); }
@@ -566,7 +567,7 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     };
     struct Cand { float ms; int tile, sp; };
     std::vector<Cand> cands;
-    for (int tile = 0; tile < 48; ++tile) {  // 4 tile shapes x 3 pipeline depths, the 256-row / 256-column tiles, the 8-wave wide tiles, fp8, the 8-wave twins of the small shapes, their loader-wave variants
+    for (int tile = 0; tile < 48 && !(p.flags & GF_GNAPPLY); ++tile) {  // 4 tile shapes x 3 pipeline depths, the 256-row / 256-column tiles, the 8-wave wide tiles, fp8, the 8-wave twins of the small shapes, their loader-wave variants
       int bm = 0, bn = 0, ns = 0;
       if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) continue;
       // fp8 tiles need the e4m3 weight copy.  An fp8 problem keeps the choice of an fp16 tile while it is small (the register-
@@ -678,6 +679,7 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
     p.splits = 1; p.kb_per_split = p.nkb;
     tile = 24 + ((p.flags & GF_GEGLU) ? (p.M >= 512 ? 0 : 3) : (p.M >= 512 ? 0 : 2));
   }
+  if (p.flags & GF_GNAPPLY) { tile = (p.Hi * p.Wi <= 256) ? 14 : 12; p.splits = 1; p.kb_per_split = p.nkb; }  // halo kernel only
   if (c->autotune) RC(tune_gemm(c, p, &tile));
   if (emit) {  // the consumer must know how many partials this launch configuration writes per row
     int bm = 0, bn = 128, ns = 0;
@@ -722,6 +724,11 @@ int Builder::conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, in
   p.flags = GF_CONV3 | (ups ? GF_UPS2 : 0) | extra_flags;
   if (tail) { p.A2 = tail->p; p.lda2 = tail->ld; p.Cin2 = w.cin2; }
   p.Wcb = w.wcb;
+  if (extra_flags & GF_GNAPPLY) {
+    if (!gn_fused.active) { dtp_set_error("conv3: GF_GNAPPLY without GroupNorm parameters"); return DTP_ERR_ARG; }
+    p.gn_part = gn_fused.part; p.gn_gamma = gn_fused.gamma; p.gn_beta = gn_fused.beta; p.gn_eps = gn_fused.eps;
+    p.gn_nchunk = gn_fused.nchunk; p.gn_cpg = gn_fused.cpg; p.gn_silu = 1;
+  }
   if (out_override) {
     y = T();
     y.p = (f16*)out_override; y.B = x.B; y.H = Ho; y.W = Wo; y.C = w.cout; y.ld = ldc_override;
@@ -736,6 +743,53 @@ int Builder::conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, in
   if (w.b || bias_step_off >= 0) { p.flags |= GF_BIAS; p.bias = w.b; }
   if (resid) { p.flags |= GF_RESID; p.R = resid->p; p.ldr = resid->ld; }
   return push_gemm(c, prog, p, bias_step_off, 9.0 * w.cin_true + w.cin2);
+}
+
+// GroupNorm (+ SiLU) followed by a 3x3 conv.  Where the conv can run on the halo kernel and the GroupNorm is the two-launch kind
+// (maps of >= 1024 pixels), the apply pass is folded into the conv (GF_GNAPPLY, conv_halo.hip): statistics pass (+ the producer's
+// split-K reduce) -> conv on the RAW tensor.  Otherwise: gn() + conv3().
+int Builder::gn_conv3(const T& x, const NormW& n, float eps, const ConvW& w, const T* resid, int bias_step_off, T& y, const T* tail, const T* dst) {
+  Ctx* cc = c;
+  const int HW = x.H * x.W, C = x.C;
+  // (bigger problems -- batched stamps, the VAE at 512^2 -- are not launch-bound: there the apply pass costs less than what the
+  // normalisation adds to every workgroup of the conv, and their tuned tiles are not the halo kernel's)
+  const bool fuse = cc->fuse_gn_conv && HW >= 1024 && x.rows() <= 16384 && w.wcb && w.taps == 9 && (C & 63) == 0 && C <= 1024 && x.C == w.cin && (C % 32) == 0 && C / 32 >= 8 &&
+                    (w.cout & 7) == 0 && (x.ld & 7) == 0;
+  if (!fuse) {
+    T t;
+    RC(gn(x, n, eps, true, t));
+    RC(conv3(t, w, 1, 1, false, x.H, x.W, resid, bias_step_off, y, 0, nullptr, 0, tail, dst));
+    release(t);
+    return DTP_OK;
+  }
+  GemmParams gp;
+  int bso = -1;
+  const bool claimed = claim_reduce(x, gp, bso);
+  const size_t slab_bytes = claimed ? ((dtp_gemm_workspace_bytes(gp) + 255) & ~(size_t)255) : 0;
+  // the partial sums outlive the statistics launch (the conv's workgroups read them while other workgroups may already write
+  // split-K slabs into the shared workspace): they get their own planned buffer
+  void* pp = nullptr;
+  RC(ctx_pool_get(cc, dtp_groupnorm_ws_bytes(x.B, HW, C, 32), &pp));
+  float* partials = (float*)pp;
+  cc->ws_need = std::max(cc->ws_need, slab_bytes);
+  const T xx = x;
+  const bool has_bias = claimed && (gp.flags & GF_BIAS) != 0;
+  push(PK_GN, 0.0, 2.0 * (double)xx.rows() * C, [=](hipStream_t s, int step) {
+    if (claimed) {
+      GnReduceSrc rd;
+      rd.part = cc->ws; rd.splits = gp.splits; rd.slab = (long long)gp.M * gp.N; rd.ldp = gp.N;
+      rd.bias = !has_bias ? nullptr : (bso >= 0 ? cc->temb_table + (size_t)step * cc->unet.temb_total + bso : gp.bias);
+      rd.R = (gp.flags & GF_RESID) ? gp.R : nullptr; rd.ldr = gp.ldr;
+      return dtp_launch_groupnorm_stats(xx.p, xx.ld, partials, xx.B, HW, C, 32, &rd, s);
+    }
+    return dtp_launch_groupnorm_stats(xx.p, xx.ld, partials, xx.B, HW, C, 32, nullptr, s);
+  }, std::string(claimed ? "reduce+gn-stats" : "gn-stats") + " B=" + std::to_string(x.B) + " HW=" + std::to_string(HW) + " C=" + std::to_string(C) + " (apply in conv)");
+  gn_fused.part = partials; gn_fused.gamma = n.g; gn_fused.beta = n.b; gn_fused.eps = eps; gn_fused.nchunk = dtp_groupnorm_stat_chunks(HW); gn_fused.cpg = C / 32;
+  gn_fused.active = true;
+  const int rc = conv3(x, w, 1, 1, false, x.H, x.W, resid, bias_step_off, y, GF_GNAPPLY, nullptr, 0, tail, dst);
+  gn_fused.active = false;
+  ctx_pool_put(cc, pp);
+  return rc;
 }
 
 int Builder::alloc_stats(long long rows, int C, RowStats& st) {
@@ -808,18 +862,14 @@ int Builder::concat(const T& a, const T& b, T& y) {
 }
 
 int Builder::resnet(const T& x, const ResW& w, float eps, bool temb, T& y, const T* dst) {
-  T t1, h, t2, sc;
-  RC(gn(x, w.n1, eps, true, t1));
-  RC(conv3(t1, w.c1, 1, 1, false, x.H, x.W, nullptr, temb ? w.temb_off : -1, h));
-  release(t1);
-  RC(gn(h, w.n2, eps, true, t2));
-  release(h);
-  if (w.has_sc) {  // conv2 and the 1x1 shortcut are one contraction: [im2col(t2) | x] . [W2 | Wsc]^T
-    RC(conv3(t2, w.c2, 1, 1, false, x.H, x.W, nullptr, -1, y, 0, nullptr, 0, &x, dst));
+  T h;
+  RC(gn_conv3(x, w.n1, eps, w.c1, nullptr, temb ? w.temb_off : -1, h, nullptr, nullptr));
+  if (w.has_sc) {  // conv2 and the 1x1 shortcut are one contraction: [im2col(GN(h)) | x] . [W2 | Wsc]^T
+    RC(gn_conv3(h, w.n2, eps, w.c2, nullptr, -1, y, &x, dst));
   } else {
-    RC(conv3(t2, w.c2, 1, 1, false, x.H, x.W, &x, -1, y, 0, nullptr, 0, nullptr, dst));
+    RC(gn_conv3(h, w.n2, eps, w.c2, &x, -1, y, nullptr, dst));
   }
-  release(t2);
+  release(h);
   return DTP_OK;
 }
 
@@ -845,6 +895,8 @@ int dtp_create(int device, int resolution, int max_batch, dtp_ctx** out) {
   tune_cache_load(c);
   if (const char* e = getenv("DTP_NO_FUSE_REDUCE_GN")) c->fuse_reduce_gn = !(e[0] && e[0] != '0');
   if (const char* e = getenv("DTP_NO_DEDUPE")) c->dedupe_prefix = !(e[0] && e[0] != '0');
+  if (const char* e = getenv("DTP_GN_CONV")) c->fuse_gn_conv = (e[0] && e[0] != '0');
+  if (const char* e = getenv("DTP_NO_XATTN")) c->fuse_xattn = !(e[0] && e[0] != '0');
   if (const char* e = getenv("DTP_NO_FOLD_GN")) c->fold_gn_linear = !(e[0] && e[0] != '0');
   *out = (dtp_ctx*)c;
   return DTP_OK;

@@ -772,6 +772,7 @@ void dtp_gemm_pick(GemmParams& p, int* tile, int num_cu) {
 
 int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
   if (p.nkb <= 0 || p.M <= 0 || p.N <= 0) { dtp_set_error("gemm: empty problem"); return DTP_ERR_ARG; }
+  if (p.flags & GF_GNAPPLY) { dtp_set_error("gemm: GroupNorm-on-the-staged-patch is a conv_halo_kernel feature (tile ids 12..15)"); return DTP_ERR_ARG; }
   if (tile == 20 || tile == 21) return dtp_launch_gemm_wide(p, tile - 20, s);
   if (tile >= 24 && tile <= 28) return dtp_launch_gemm_fp8(p, tile - 24, s);
   if ((p.lda & 7) || (p.ldw & 7)) { dtp_set_error("gemm: lda/ldw must be multiples of 8"); return DTP_ERR_ARG; }

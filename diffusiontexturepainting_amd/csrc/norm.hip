@@ -554,6 +554,8 @@ static int gn_chunks(int HW) {  // pixel chunks per batch item for the statistic
   return n;
 }
 
+int dtp_groupnorm_stat_chunks(int HW) { return gn_chunks(HW); }
+
 size_t dtp_groupnorm_ws_bytes(int B, int HW, int C, int groups) {
   return (size_t)B * std::max(gn_chunks(HW), gn_chunks_reduce(HW)) * groups * 2 * sizeof(float);
 }

@@ -310,6 +310,7 @@ int dtp_finalize_weights(dtp_ctx* ctx) {
   dtp_conv_halo_init();
   dtp_gemm_wide_init();
   dtp_gemm_fp8_init();
+  dtp_xattn_init();
   RC(load_unet_weights(c));
   RC(load_vae_weights(c));
   bool has_clip = false;
@@ -561,6 +562,14 @@ int dtp_set_option(dtp_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "use_graph")) { c->use_graph = value != 0; return DTP_OK; }
   if (!strcmp(name, "autotune")) { c->autotune = value != 0; return DTP_OK; }
   if (!strcmp(name, "check_finite")) { c->check_finite = value != 0; return DTP_OK; }
+  if (!strcmp(name, "fuse_gn_conv")) {
+    if (!c->unet_progs.empty() || !c->enc_progs.empty() || !c->dec_progs.empty()) {
+      dtp_set_error("dtp_set_option: fuse_gn_conv must be chosen before the first launch program is built");
+      return DTP_ERR_STATE;
+    }
+    c->fuse_gn_conv = value != 0;
+    return DTP_OK;
+  }
   if (!strcmp(name, "dedupe_prefix")) {  // programs are keyed by it: switching only affects which (cached) program a stamp uses
     c->dedupe_prefix = value != 0;
     for (auto& g : c->graphs) {  // captured stages hold the old program's launches

@@ -236,7 +236,31 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
   b.release(a); b.release(y);
   // Cross-attention over 14 context tokens: softmax_j(LN2(y2) Wq'^T K^T) V Wo^T collapses to two grouped GEMMs against
   // per-sample matrices prepared once per stamp (UNetProg::xW1 / xW2): scores + group softmax, then the value-output product.
+  XattnParams xp = {};
   {
+    const int i = w.kv_index, Cp = (C + 127) / 128 * 128;
+    xp.X = y2.p; xp.ldx = y2.ld; xp.W1 = up.xW1[i]; xp.w1_bs = (long long)128 * C; xp.b1 = up.xb1[i]; xp.lns1 = up.xl1[i];
+    xp.st_in = st2.buf; xp.st_parts = st2.parts; xp.st_rows = N * S; xp.ln_eps = 1e-5f;
+    xp.W2 = up.xW2[i]; xp.w2_bs = (long long)Cp * 128; xp.b2 = w.out2.b; xp.R = y2.p; xp.ldr = y2.ld;
+    xp.S = S; xp.C = C; xp.N = N; xp.sm_valid = 14; xp.zero = b.c->zero;
+  }
+  // The fused kernel recomputes the score tile once per 128-column tile of the output: it pays where the pair is launch-bound (few
+  // workgroups: levels 1-3 of a batch-1 stamp, every level at 256^2) and loses where the grid already fills the chip several times
+  // (level 0 at 512^2: +1.3 ms per stamp; batch 8: +17 ms per batch with everything fused -- same-box A/B).
+  const long long xa_wgs = (long long)((S + 63) / 64) * ((C + 127) / 128) * N;
+  if (b.c->fuse_xattn && xa_wgs <= 2LL * b.c->num_cu && st2.buf && st2.parts > 0 && st2.M == N * S && dtp_xattn_supported(xp)) {
+    // one launch: scores + group softmax + value-output product + residual (xattn.hip); the probabilities never leave LDS
+    RC(b.alloc_stats((long long)N * S, C, st3));
+    y3 = b.alloc(N, x.H, x.W, C);
+    if (!y3.p) return DTP_ERR_HIP;
+    xp.Y = y3.p; xp.ldy = y3.ld; xp.st_out = st3.buf;
+    st3.parts = (C + 127) / 128; st3.M = N * S;
+    const double tiles = (double)((C + 127) / 128);
+    b.push(PK_XATTN, 2.0 * N * S * 128.0 * C * (tiles + 1.0), 2.0 * N * (3.0 * S * C + 2.0 * 128 * C),
+           [=](hipStream_t s, int) { return dtp_launch_xattn(xp, s); }, "xattn M=" + std::to_string(S) + " C=" + std::to_string(C) + " x" + std::to_string(N));
+    b.release_stats(st2);
+    b.release(y2);
+  } else {
     const int i = w.kv_index, Cp = (C + 127) / 128 * 128;
     T pm = b.alloc(N, x.H, x.W, 128);  // probabilities [rows][8 heads x 16 (14 valid)]
     if (!pm.p) return DTP_ERR_HIP;

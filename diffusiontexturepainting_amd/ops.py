@@ -164,6 +164,19 @@ def reduce_groupnorm(part, gamma, beta, bias=None, resid=None, groups=32, eps=1e
     return out, y
 
 
+def xattn(x, w1, b1, lns1, st_in, w2, b2, n_samples, sm_valid=14, ln_eps=1e-5, row_stats=False):
+    """Fused cross-attention GEMM pair (xattn.hip): x f16 [N*S, C]; w1 f16 [N*128, C]; b1 / lns1 f32 [N*128]; st_in f32 [parts, N*S, 2];
+    w2 f16 [N*roundup(C,128), 128]; b2 f32 [C] -> y f16 [N*S, C] (and the [ceil(C/128), N*S, 2] row-statistics partials)."""
+    lib = _lib.load()
+    rows, c = x.shape
+    s = rows // n_samples
+    y = torch.empty_like(x)
+    st = torch.zeros((c + 127) // 128, rows, 2, dtype=torch.float32, device=x.device) if row_stats else None
+    check(lib.dtp_op_xattn(ptr(x), ptr(w1), ptr(b1), ptr(lns1), ptr(st_in), st_in.shape[0], ptr(w2), ptr(b2), ptr(x), ptr(y), ptr(st), s, c, n_samples,
+                           sm_valid, ln_eps, _stream()), "xattn")
+    return (y, st) if row_stats else y
+
+
 def gn_fold_weights(x, wp, n_out, bias, gamma, beta, groups=32, eps=1e-6):
     """x f16 [B,HW,C], wp packed f16 [rows, ldw] -> (per-sample packed weights f16 [B, rows, ldw], biases f32 [B, rows]) such that
     proj(GroupNorm(x_b)) == x_b @ W_b^T + b_b (GroupNorm without activation folded into its consumer)."""

@@ -211,6 +211,12 @@ int dtp_op_measure_peaks(double* mfma_f16_tflops, double* hbm_copy_gbs);
  * behind a conv); one launch for HW <= 256, reduce-in-statistics + apply above */
 int dtp_op_reduce_groupnorm(const float* part, int splits, const float* bias, const void* resid, void* conv_out, void* y, const float* gamma,
                             const float* beta, int B, int HW, int C, int groups, float eps, int silu, dtp_stream s);
+/* the two grouped GEMMs of the algebraically fused cross-attention (attn2 of BasicTransformerBlock against 14 context tokens) as ONE
+ * launch: Y = softmax_16(LN(X) W1^T + b1) W2^T + b2 + R per sample.  X / R / Y f16 [N*S][C]; W1 f16 [N][128][C] (LayerNorm gamma
+ * folded in), b1 / lns1 f32 [N][128]; st_in f32 [st_parts][N*S][2] = per-row (sum, sumsq) partials of X; W2 f16 [N][roundup(C,128)][128];
+ * st_out f32 [ceil(C/128)][N*S][2] (or null) = the same partials of Y for the next LayerNorm-folded GEMM */
+int dtp_op_xattn(const void* X, const void* W1, const float* b1, const float* lns1, const float* st_in, int st_parts, const void* W2, const float* b2,
+                 const void* R, void* Y, float* st_out, int S, int C, int N, int sm_valid, float ln_eps, dtp_stream s);
 /* GroupNorm (no activation) folded into the Linear / 1x1 conv that consumes it (Transformer2DModel: norm -> proj_in): from x f16
  * [B][HW][C] and the packed weights W f16 [rows][ldw] (+ bias[Nout]) compute per-sample Wout f16 [B][rows][ldw] = W diag(gamma * rstd_b)
  * and bias_out f32 [B][rows] = bias + W (beta - mean_b * rstd_b * gamma), rows = roundup(Nout, 128): proj(GN(x_b)) == Wout_b x_b + bias_out_b */

@@ -187,3 +187,25 @@ def test_deduplicated_prefix_is_bit_identical(weights):
         assert torch.equal(outs[(1, b)][0], outs[(0, b)][0]), (outs[(1, b)][0] - outs[(0, b)][0]).abs().max()
         assert torch.isfinite(outs[(1, b)][0]).all() and outs[(1, b)][0].std() > 1e-3
         assert outs[(1, b)][1] == outs[(0, b)][1] + 4  # one row-copy launch per evaluation (4 evaluations), nothing else changes
+
+
+def test_groupnorm_applied_on_the_conv_input_patch(weights):
+    """Option fuse_gn_conv (off by default: it measured slower): GroupNorm + SiLU of a ResBlock applied by conv_halo_kernel on its
+    staged input patch instead of by an apply launch.  A 256^2 stamp with the option on must still match the oracle (level 0 of this
+    resolution has the 1024-pixel maps the fused path takes), and must differ from the default path only by fp16 roundings."""
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    from oracle import pipeline
+    canvas, brush, cond, uncond, lat, eps = _inputs(1, 256, 900)
+    st = dict(steps=4, context_pad=150, tg_steps=4, cfg_weight=2.0, tg_weight=1.0)
+    outs = []
+    for on in (1, 0):
+        m = MI355ConditionalInpainter(256, device=0, weights=weights[0], max_batch=1)
+        m.set_option("fuse_gn_conv", on)
+        m.set_conditioning(cond, uncond, brush)
+        outs.append((m.generate_raw(canvas, latents=lat, vae_eps=eps, **st).cpu(), m.stamp_info()["graph_nodes"]))
+        del m
+    ref = pipeline.generate_raw(weights[1], brush, cond, uncond, canvas, lat, eps, **st)
+    assert (outs[0][0] - ref).abs().max().item() <= 1e-2 and (outs[1][0] - ref).abs().max().item() <= 1e-2
+    assert outs[0][1] < outs[1][1]                       # fewer launches: the apply passes are gone ...
+    assert not torch.equal(outs[0][0], outs[1][0])       # ... and the option really switched the kernels
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 5e-3

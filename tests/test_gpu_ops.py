@@ -143,6 +143,48 @@ def test_gemm_batched_group_softmax(ops, tile):
     close(got, ref.view(nb * m, 128), tol=3e-3)
 
 
+@pytest.mark.parametrize("nb,s,c", [(3, 4096, 320), (3, 1024, 640), (3, 256, 1280), (2, 64, 1280), (3, 200, 320), (1, 16, 1280), (6, 4, 640)])
+def test_fused_cross_attention_pair_matches_the_two_gemms(ops, nb, s, c):
+    """xattn_kernel = scores GEMM (LayerNorm fold from the producer's row statistics, group softmax) + value-output GEMM (bias,
+    residual, row statistics for the next fold) in one launch.  Same MFMA order and the same fp16 rounding points as the unfused pair
+    (only the fp32 epilogue expressions may be contracted differently by the compiler): outputs within one fp16 step of it, the
+    statistics partials consistent with the stored rows, and both against torch."""
+    from diffusiontexturepainting_amd._lib import GF_BIAS, GF_SOFTMAX16
+    g = torch.Generator().manual_seed(77)
+    x = (rnd(nb * s, c, seed=78) * 1.3 + 0.2).cuda()
+    w1 = rnd(nb, 128, c, seed=79, scale=2.0 * c ** -0.5).float()
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    b1 = 0.3 * torch.randn(nb, 128, generator=g)
+    w2 = rnd(nb, c, 128, seed=80, scale=0.1).float()
+    b2 = torch.randn(c, generator=g)
+    # the producer's row statistics: (sum, sumsq) of x in two arbitrary column parts
+    xf = x.float().cpu()
+    h = c // 2
+    st_in = torch.stack([torch.stack([xf[:, :h].sum(1), (xf[:, :h] ** 2).sum(1)], dim=1),
+                         torch.stack([xf[:, h:].sum(1), (xf[:, h:] ** 2).sum(1)], dim=1)]).cuda()
+    w1p = torch.cat([ops.pack_linear((w1[b] * gamma[None]).cuda()) for b in range(nb)], dim=0).contiguous()
+    b1f = (b1 + torch.einsum("bnc,c->bn", w1, beta)).reshape(-1).cuda()
+    lns = ops.rowsum(w1p, c)
+    w2p = torch.cat([ops.pack_linear(w2[b].cuda()) for b in range(nb)], dim=0).contiguous()
+    # unfused pair on tile 3 (64 x 128, two stages, 4 waves)
+    pm = ops.gemm(x, w1p, 128, c, bias=b1f, lns=lns, tile=3, flags=GF_BIAS | GF_SOFTMAX16, batch=nb, sm_valid=14, stats_in=st_in)
+    ref_y, ref_st = ops.gemm(pm, w2p, c, 128, bias=b2.cuda(), resid=x, tile=3, batch=nb, bias_shared=True, row_stats=True)
+    got_y, got_st = ops.xattn(x, w1p, b1f, lns, st_in, w2p, b2.cuda(), nb, row_stats=True)
+    d = (got_y.float() - ref_y.float()).abs()
+    assert d.max().item() <= 2.0 ** -7 * max(1.0, ref_y.float().abs().max().item()) and (d > 0).float().mean().item() < 0.05
+    # the partials are the (sum, sumsq) of the STORED fp16 rows, per 128-column tile
+    yf = got_y.float()
+    for t in range(got_st.shape[0]):
+        blk = yf[:, 128 * t:128 * (t + 1)]
+        assert torch.allclose(got_st[t, :, 0], blk.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(got_st[t, :, 1], (blk * blk).sum(1), rtol=1e-4, atol=1e-2)
+    xn = F.layer_norm(xf, (c,), gamma, beta, 1e-5).view(nb, s, c)
+    sc = (torch.einsum("bmc,bnc->bmn", xn, w1) + b1[:, None]).view(nb, s, 8, 16)
+    pr = torch.zeros_like(sc)
+    pr[..., :14] = torch.softmax(sc[..., :14], dim=-1)
+    ref = torch.einsum("bmk,bnk->bmn", pr.view(nb, s, 128), w2).reshape(nb * s, c) + b2 + xf
+    close(got_y, ref, tol=4e-3)
+
+
 def test_gemm_batched_residual(ops):
     """Second half: P [b*M, 128] times a per-entry [N, 128] matrix, + bias + residual."""
     nb, m, n = 3, 130, 320

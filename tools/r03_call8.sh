@@ -1,0 +1,12 @@
+export DTP_TUNE_CACHE=/tmp/tc.txt
+timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -k "cross_attention or batched" > gpurun_out/r03_ops6.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_engine.py -x -q > gpurun_out/r03_engine6.log 2>&1
+timeout 600 python bench.py --no-cpu-baseline --no-extras --no-profile > /dev/null 2>&1
+for i in 1 2; do
+DTP_NO_XATTN=1 timeout 600 python bench.py --no-cpu-baseline --no-extras --no-profile > gpurun_out/r03_xa0_b1_$i.log 2>&1
+timeout 600 python bench.py --no-cpu-baseline --no-extras --no-profile > gpurun_out/r03_xa1_b1_$i.log 2>&1
+done
+DTP_NO_XATTN=1 timeout 600 python bench.py --res 256 --no-cpu-baseline --no-extras --no-profile > gpurun_out/r03_xa0_256.log 2>&1
+timeout 600 python bench.py --res 256 --no-cpu-baseline --no-extras --no-profile > gpurun_out/r03_xa1_256.log 2>&1
+DTP_NO_XATTN=1 timeout 600 python bench.py --batch 8 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-profile > gpurun_out/r03_xa0_b8.log 2>&1
+timeout 600 python bench.py --batch 8 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-profile > gpurun_out/r03_xa1_b8.log 2>&1
