@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PMC_TRAFFIC_FILE = "r03_pmc_unet_traffic.json"  # tools/pmc_unet.sh, committed with the sha1 of the kernel sources it was collected on
 
 
 def cpu_baseline(res, ddim_steps, weights, budget_note):
@@ -89,15 +90,15 @@ def pmc_traffic(batch):
     (profiles/, collected by tools/pmc_unet.sh on eager UNet evaluations: counters cannot be read from inside this process).
     The summary carries the kernel-source hash it was collected on; if the running build differs, traffic is reported as null
     (a stale number is worse than none)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_unet_traffic.json")
+    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
     if batch != 1 or not os.path.exists(path):
         return {"traffic": None}
     t = json.load(open(path))
     if t.get("kernel_source_hash") != kernel_source_hash():
-        return {"traffic": None, "traffic_note": f"profiles/r02_pmc_unet_traffic.json was collected on build {t.get('kernel_source_hash')}, "
+        return {"traffic": None, "traffic_note": f"profiles/{PMC_TRAFFIC_FILE} was collected on build {t.get('kernel_source_hash')}, "
                                                  f"this build is {kernel_source_hash()}: not reported"}
     return {"traffic": t["traffic_bytes_per_launch"], "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
-            "traffic_source": "profiles/r02_pmc_unet_traffic.json", "traffic_kernel_source_hash": t["kernel_source_hash"]}
+            "traffic_source": f"profiles/{PMC_TRAFFIC_FILE}", "traffic_kernel_source_hash": t["kernel_source_hash"]}
 
 
 def measured_peaks():
@@ -358,12 +359,12 @@ def main():
             model.profile_dump(a.dump_launches)
         model.profile(False)
         tot_ms = sum(r["ms"] for r in rows)
-        gem = [r for r in rows if r["kernel"].startswith(("gemm_kernel", "conv_halo_kernel", "gemm_wide_kernel"))]
+        gem = [r for r in rows if r["kernel"].startswith(("gemm_kernel", "conv_halo_kernel", "gemm_wide_kernel", "xattn_kernel"))]
         # dominant kernel = the implicit-GEMM kernel; its most time-consuming instantiation is the headline row
         dom = max(gem, key=lambda r: r["ms"])
         g_ms, g_fl, g_n = sum(r["ms"] for r in gem), sum(r["flops"] for r in gem), sum(r["launches"] for r in gem)
         roof = {
-            "bound": "mfma", "kernel": "gemm_kernel<BM,BN,NS> + gemm_wide_kernel<BM,BN> + conv_halo_kernel<TH,TW,BN> (implicit-GEMM conv/linear, all instantiations)",
+            "bound": "mfma", "kernel": "gemm_kernel<BM,BN,NS,KH,LW> + gemm_wide_kernel<BM,BN> + conv_halo_kernel<TH,TW,BN> + xattn_kernel (implicit-GEMM conv/linear, all instantiations)",
             "achieved": g_fl / (g_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": g_fl / (g_ms * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS,
             "peak_measured": peak_tf, "frac_of_measured": g_fl / (g_ms * 1e-3) / 1e12 / peak_tf,

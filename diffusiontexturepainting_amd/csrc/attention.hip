@@ -54,9 +54,12 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, hf = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
+  // p.hb_major: grid.x = head x batch, grid.y = query block -> block id % 8 (= the XCD) is a function of (head, batch) alone, so the
+  // 32 query blocks that stream the same K / V all run behind ONE L2 (otherwise every head's K / V is pulled into all eight)
+  const int h = p.hb_major ? (int)(blockIdx.x % p.H) : (int)blockIdx.y, b = p.hb_major ? (int)(blockIdx.x / p.H) : (int)blockIdx.z;
+  const int qblk = p.hb_major ? blockIdx.y : blockIdx.x;
   const int D = p.D;
-  const int q = blockIdx.x * 128 + wave * 32 + lq;
+  const int q = qblk * 128 + wave * 32 + lq;
   const f16* Qb = p.Q + p.qbs * b + h * D;
   const f16* Kb = p.K + p.kbs * b + h * D;
   const f16* Vb = p.V + p.vbs * b + h * D;
@@ -122,15 +125,23 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
     vkv[it] = vval[it] ? 2 * pr : 0;
     vsrc[it] = Vb + (vval[it] ? c * 8 : 0);
   }
-  auto prefetch = [&](int kv0) {
+  // running staging pointers of the current tile (advanced by 64 rows per tile): the row index times the row stride recomputed per
+  // tile was ~20 multi-cycle 64-bit VALU instructions in a loop whose VALU issue is the bound (PMC: VALU issue 50 % of SIMD cycles)
+  const f16* kcur[KIT]; const f16* vcur[VIT];
+#pragma unroll
+  for (int it = 0; it < KIT; ++it) kcur[it] = ksrc[it] + (size_t)kkv[it] * p.ldk;
+#pragma unroll
+  for (int it = 0; it < VIT; ++it) vcur[it] = vsrc[it] + (size_t)vkv[it] * p.ldv;
+  const size_t kstep = (size_t)64 * p.ldk, vstep = (size_t)64 * p.ldv;
+  auto prefetch = [&](int kv0) {  // called with kv0 = 0, 64, 128, ... in order
     if (kv0 + 64 <= p.Skv) {  // full tile (wave-uniform)
 #pragma unroll
-      for (int it = 0; it < KIT; ++it) kreg[it] = *(const f16x8*)(ksrc[it] + (size_t)(kv0 + kkv[it]) * p.ldk);
+      for (int it = 0; it < KIT; ++it) { kreg[it] = *(const f16x8*)kcur[it]; kcur[it] += kstep; }
 #pragma unroll
       for (int it = 0; it < VIT; ++it) {
-        const f16* v0 = vsrc[it] + (size_t)(kv0 + vkv[it]) * p.ldv;
-        vreg[it][0] = *(const f16x8*)v0;
-        vreg[it][1] = *(const f16x8*)(v0 + p.ldv);
+        vreg[it][0] = *(const f16x8*)vcur[it];
+        vreg[it][1] = *(const f16x8*)(vcur[it] + p.ldv);
+        vcur[it] += vstep;
       }
     } else {
       const int last = p.Skv - 1;
@@ -168,6 +179,11 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
     }
   };
 
+  // experiment ($DTP_ATTN_SKEW=n): co-resident workgroups start in lockstep and run equal-length phases, so the waves of a SIMD ask
+  // for the matrix pipe (and then for the VALU) all at once; delaying every other workgroup by n * 64 cycles de-phases them
+  if (p.skew > 0 && (blockIdx.x & 1)) {
+    for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   const char* const kfrag0 = Kl + lq * KROW + hf * 16;  // this lane's K / V^T fragment rows (buffer 0)
   const char* const vfrag0 = Vl + lq * VROW + hf * 16;
   prefetch(0);
@@ -321,11 +337,16 @@ int dtp_launch_attention(const AttnParams& pin, hipStream_t s) {
   // samples, neutral at batch 8; tools/diag_attn.py).  $DTP_ATTN_PRIO overrides (0 = off) for A/B.
   static const int prio_env = [] { const char* e = getenv("DTP_ATTN_PRIO"); return e ? atoi(e) : 3; }();
   p.prio = prio_env;
+  static const int skew_env = [] { const char* e = getenv("DTP_ATTN_SKEW"); return e ? atoi(e) : 0; }();
+  p.skew = skew_env;
   if ((p.D & 7) || (p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.ldo & 3) || p.Skv < 1 || p.Sq < 1) {
     dtp_set_error("attention: D=%d ldq=%d ldk=%d ldv=%d ldo=%d unsupported", p.D, p.ldq, p.ldk, p.ldv, p.ldo);
     return DTP_ERR_ARG;
   }
+  static const bool hb_env = [] { const char* e = getenv("DTP_ATTN_HBMAJOR"); return !(e && e[0] == '0'); }();
+  p.hb_major = hb_env && ((p.H * p.B) % 8) == 0 && (p.Sq + 127) / 128 >= 8 ? 1 : 0;
   dim3 grid((p.Sq + 127) / 128, p.H, p.B), block(256);
+  if (p.hb_major) grid = dim3(p.H * p.B, (p.Sq + 127) / 128, 1);
   static const int cus = [] {
     int dev = 0;
     hipDeviceProp_t prop;

@@ -118,6 +118,7 @@ enum {
   GF_SOFTMAX16 = 4096,// epilogue: softmax over each aligned group of 16 output columns (first sm_valid of them; the rest -> 0)
   GF_MFAST = 1 << 20,// internal: tile_m varies fastest (neighbouring workgroups share the W panel)
   GF_NOREDUCE = 1 << 21,// internal: a split launch leaves its fp32 slabs for the consumer (fused reduce + GroupNorm)
+  GF_XCDSPLIT = 1 << 23,// internal (set by the launcher): 1-D grid of tiles x splits blocks, K-slice z pinned to XCD z % 8 (see dtp_xcd_split)
   GF_GNAPPLY = 1 << 22, // conv_halo_kernel only: A is the RAW pre-GroupNorm tensor; the staged input patch is normalised (+ SiLU) in LDS
                         // from the statistics partials gn_part (GemmParams::gn_*): no apply launch, no normalised tensor
 };
@@ -163,6 +164,21 @@ struct GemmParams {
   float a_scale, w_scale;  // A8 = e4m3(A / a_scale), W8 = e4m3(W / w_scale); powers of two
 };
 
+// K-slices pinned to XCDs.  Block b of a launch runs on XCD b % 8 and every XCD has its own L2: with the split index on grid.z the
+// tiles of one K-slice are spread over all XCDs, so each slice's operand panels are fetched from the Infinity Cache / HBM into up to
+// eight L2s (the shared panels of a level-2 conv: ~6x its weights).  With a 1-D grid and slice z on XCD z % 8 (S >= 8) -- or a slice
+// on 8 / S XCDs (S = 2, 4) -- a panel crosses into exactly the L2(s) of its slice.  Applies when S is a power of two and the
+// blocks divide evenly; otherwise the launcher keeps grid.z.
+static inline bool dtp_xcd_split_ok(int tiles, int splits) {
+  if (splits < 2 || (splits & (splits - 1)) || splits > 32) return false;
+  return splits >= 8 || (tiles % (8 / splits)) == 0;
+}
+static __device__ __forceinline__ void dtp_xcd_split(int id, int tiles, int splits, int& tile, int& z) {
+  const int xcd = id & 7, idx = id >> 3;
+  if (splits >= 8) { const int r = splits >> 3; z = xcd + 8 * (idx % r); tile = idx / r; }
+  else { const int g = 8 / splits; z = xcd % splits; tile = idx * g + xcd / splits; }
+}
+
 // tile: shape + 4 * (stages - 2); shape 0 = 128x128, 1 = 128(M)x64(N), 2 = 64x64, 3 = 64(M)x128(N); stages 2..4
 int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s);
 int dtp_launch_splitk_reduce(const GemmParams& p, hipStream_t s);
@@ -204,7 +220,9 @@ struct AttnParams {
   int B, H, Sq, Skv, D;         // head h reads columns [h*D, (h+1)*D)
   long long qbs, kbs, vbs, obs; // batch strides (elements)
   float scale;
-  int prio;  // experiment ($DTP_ATTN_PRIO): raise the wave priority around the MFMA clusters
+  int prio;  // $DTP_ATTN_PRIO: raise the wave priority around the MFMA clusters
+  int hb_major;  // set by the launcher: grid.x = head x batch (all query blocks of a head behind one XCD's L2)
+  int skew;  // experiment ($DTP_ATTN_SKEW): start delay of every other workgroup, in units of 64 cycles
 };
 int dtp_launch_attention(const AttnParams& p, hipStream_t s);
 // attention_fp8.hip: the same contraction on the fp8 (e4m3) MX MFMA; q_scale / v_scale = per-tensor scales (powers of two)

@@ -9,6 +9,7 @@
 // Same MFMA mapping, LDS swizzle, epilogue and split-K convention as gemm_kernel (see gemm_conv.hip); the
 // pipeline is: weights in a 3-deep ring (counted vmcnt, raw s_barrier per tap), halo double-buffered and
 // refilled during tap 0 of the previous channel block.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -59,8 +60,9 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, tiles_n = (p.N + BN - 1) / BN;
   const int nimg = p.M / (H * W);
   const int nwg = nimg * tiles_y * tiles_x * tiles_n;
-  int wg;
-  {
+  int wg, zid = blockIdx.z;
+  if (p.flags & GF_XCDSPLIT) dtp_xcd_split(blockIdx.x, nwg, p.splits, wg, zid);  // K-slice zid lives on XCD zid % 8 (common.h)
+  else {
     const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
   // k-block sequence: nmain = 9 per 64-channel block (channel-block-major), then Cin2/64 dense "shortcut" blocks that
   // read the ResBlock input A2 at the output pixel itself (the fused 1x1 conv).  Split-K cuts this sequence anywhere.
   const int ncb = p.Cin >> 6, nmain = ncb * 9, ntail = p.A2 ? (p.Cin2 >> 6) : 0, ntot = nmain + ntail;
-  const int ita = blockIdx.z * p.kb_per_split;
+  const int ita = zid * p.kb_per_split;
   const int nit = min(p.kb_per_split, ntot - ita);
   const int itb = ita + nit;
 
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
     return ((size_t)img * H + y) * W + x;
   };
   if (p.splits > 1) {
-    float* part = p.part + (size_t)blockIdx.z * p.M * p.N;
+    float* part = p.part + (size_t)zid * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -382,14 +384,19 @@ constexpr int halo_lds() {
 constexpr int GN_MAX_CIN = 1024;  // (scale, shift) table: 8 KB at most, so that the 8x16 x 64 variant still fits twice on a CU
 
 template <int TH, int TW, int BN>
-int launch_halo(const GemmParams& p, hipStream_t s) {
+int launch_halo(const GemmParams& pin, hipStream_t s) {
+  GemmParams p = pin;
   const int H = p.Hi, W = p.Wi;
   const int blocks = (p.M / (H * W)) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * ((p.N + BN - 1) / BN);
   constexpr int lds = halo_lds<TH, TW, BN>();
+  static const bool xcd_off = [] { const char* e = getenv("DTP_NO_XCD_SPLIT"); return e && e[0] && e[0] != '0'; }();
+  const bool xs = !xcd_off && dtp_xcd_split_ok(blocks, p.splits);
+  if (xs) p.flags |= GF_XCDSPLIT;
+  const dim3 grid = xs ? dim3(blocks * p.splits, 1, 1) : dim3(blocks, 1, p.splits);
   if (p.flags & GF_GNAPPLY)
-    hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, true>), dim3(blocks, 1, p.splits), dim3(256), lds + p.Cin * 8 + 256, s, p);
+    hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, true>), grid, dim3(256), lds + p.Cin * 8 + 256, s, p);
   else
-    hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, false>), dim3(blocks, 1, p.splits), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, false>), grid, dim3(256), lds, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 

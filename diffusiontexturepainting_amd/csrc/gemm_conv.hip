@@ -16,6 +16,7 @@
 // up holding 4 consecutive output channels of one token -> 8-byte LDS writes into a staging
 // tile and fully coalesced 16-byte global stores with bias / residual / GEGLU fused.
 // Workgroup ids are remapped so each XCD (private L2) owns a contiguous range of tiles.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -80,8 +81,9 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
   // ---- XCD-aware tile assignment (bijective remap; block b runs on XCD b % 8)
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
-  int wg;
-  {
+  int wg, zid = blockIdx.z;
+  if (p.flags & GF_XCDSPLIT) dtp_xcd_split(blockIdx.x, nwg, p.splits, wg, zid);  // K-slice zid lives on XCD zid % 8 (common.h)
+  else {
     const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
   if (p.flags & GF_MFAST) { tile_n = wg / tiles_m; tile_m = wg - tile_n * tiles_m; }
   else { tile_m = wg / tiles_n; tile_n = wg - tile_m * tiles_n; }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int kb0 = blockIdx.z * p.kb_per_split;
+  const int kb0 = zid * p.kb_per_split;
   const int nk = min(p.kb_per_split, p.nkb - kb0);
 
   // ---- DMA source state.  Row r = i*RPR + wave*8 + (lane>>3); LDS slot = lane&7 holds source
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
   // D layout (32x32): lane holds column (lane&31) = token, rows (r&3)+8*(r>>2)+4*(lane>>5) = channel.
   if (p.splits > 1) {
     if (kh != 0) return;
-    float* part = p.part + (size_t)blockIdx.z * p.M * p.N;
+    float* part = p.part + (size_t)zid * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -670,12 +672,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
 }
 
 template <int BM, int BN, int NS, int KH, int LW, bool CONV>
-int launch_tile_mode(const GemmParams& p, hipStream_t s) {
+int launch_tile_mode(const GemmParams& pin, hipStream_t s) {
+  GemmParams p = pin;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  static const bool xcd_off = [] { const char* e = getenv("DTP_NO_XCD_SPLIT"); return e && e[0] && e[0] != '0'; }();
+  const bool xs = !xcd_off && p.batch <= 1 && dtp_xcd_split_ok(tiles, p.splits);
+  if (xs) p.flags |= GF_XCDSPLIT;
   constexpr int lds = NS * (BM + BN) * 128 + BM * 8;  // + per-row LayerNorm statistics
   static_assert(lds - BM * 8 >= BM * (BN + 8) * 2, "staging tile must fit in the pipeline buffers");
   static_assert(lds <= 160 * 1024, "LDS budget");
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS, KH, LW, CONV>), dim3(tiles, p.batch > 1 ? p.batch : 1, p.splits), dim3(256 * KH + 64 * LW), lds, s, p);
+  const dim3 grid = xs ? dim3(tiles * p.splits, 1, 1) : dim3(tiles, p.batch > 1 ? p.batch : 1, p.splits);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS, KH, LW, CONV>), grid, dim3(256 * KH + 64 * LW), lds, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 

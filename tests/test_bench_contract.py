@@ -42,7 +42,7 @@ def test_pmc_traffic_is_tied_to_the_build_it_was_collected_on():
     """bench.py may only report the committed PMC traffic figure when the kernel sources are the ones it was collected on."""
     bench = _bench()
     assert bench.pmc_traffic(8) == {"traffic": None}  # collected for the B=1 workload only
-    path = os.path.join(ROOT, "profiles", "r02_pmc_unet_traffic.json")
+    path = os.path.join(ROOT, "profiles", bench.PMC_TRAFFIC_FILE)
     t = bench.pmc_traffic(1)
     if not os.path.exists(path):
         assert t == {"traffic": None}

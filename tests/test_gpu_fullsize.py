@@ -97,21 +97,22 @@ def test_config2_batch8_consistent_with_single_stamps(model512):
         assert err <= 1e-2
 
 
-def test_256_20steps_matches_cpu_oracle(weights):
-    """The reference server's own operating point (run.py:30: resolution 256; Kit default 20 steps): 19 UNet evaluations of
-    accumulated fp16 error against the fp32 oracle (about a minute of host time)."""
+def test_256_10steps_matches_cpu_oracle(weights):
+    """The reference server's own resolution (run.py:30: 256): 9 UNet evaluations of accumulated fp16 error against the fp32 oracle,
+    texture guidance cut off mid-loop so both launch programs run (the 19-evaluation case is the 512^2 test below; this one was 20
+    steps until the full-size test joined the default set and the GPU leg needed the minute back)."""
     from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
     from oracle import pipeline
     m = MI355ConditionalInpainter(256, device=0, weights=weights[0], max_batch=1)
     canvas, brush, cond, uncond, lat, eps = _inputs(1, 256, 500)
-    st = dict(steps=20, context_pad=150, tg_steps=5, cfg_weight=2.0, tg_weight=1.0)  # tg cut-off mid-loop: both programs run
+    st = dict(steps=10, context_pad=150, tg_steps=4, cfg_weight=2.0, tg_weight=1.0)  # tg cut-off mid-loop: both programs run
     m.set_conditioning(cond, uncond, brush)
     got = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
     torch.cuda.synchronize()
     ref = pipeline.generate_raw(weights[1], brush, cond, uncond, canvas, lat, eps, **st)
     err = (got.cpu() - ref).abs().max().item()
-    print("256^2 / 20 steps: max abs pixel error", err, "stage ms", m.stage_times_ms())
-    assert err <= 1e-2 and m.stamp_info()["unet_evals"] == 19
+    print("256^2 / 10 steps: max abs pixel error", err, "stage ms", m.stage_times_ms())
+    assert err <= 1e-2 and m.stamp_info()["unet_evals"] == 9
 
 
 FP8_ATTN_PIXEL_TOL = 3e-2  # BASELINE configs[4], attention only: fp8 (e4m3) operands cost more than the 1e-2 of the fp16 path

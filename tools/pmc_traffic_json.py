@@ -8,7 +8,7 @@ spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "b
 bench = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bench)
 
-GEMM = ("gemm_kernel<", "conv_halo_kernel<", "gemm_wide_kernel<")
+GEMM = ("gemm_kernel<", "conv_halo_kernel<", "gemm_wide_kernel<", "xattn_kernel")
 
 
 def total(path, counter):
