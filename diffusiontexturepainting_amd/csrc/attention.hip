@@ -54,10 +54,9 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, hf = lane >> 5;
-  // p.hb_major: grid.x = head x batch, grid.y = query block -> block id % 8 (= the XCD) is a function of (head, batch) alone, so the
-  // 32 query blocks that stream the same K / V all run behind ONE L2 (otherwise every head's K / V is pulled into all eight)
-  const int h = p.hb_major ? (int)(blockIdx.x % p.H) : (int)blockIdx.y, b = p.hb_major ? (int)(blockIdx.x / p.H) : (int)blockIdx.z;
-  const int qblk = p.hb_major ? blockIdx.y : blockIdx.x;
+  // (a 1-D grid that keeps all query blocks of a (head, batch) pair behind one XCD's L2 measured neutral at batch 1 and 8 -- the
+  // kernel is VALU-issue-bound, not K / V-fetch-bound; a grid that walks all heads per query block thrashes: 757 -> 1454 us at batch 8)
+  const int h = blockIdx.y, b = blockIdx.z, qblk = blockIdx.x;
   const int D = p.D;
   const int q = qblk * 128 + wave * 32 + lq;
   const f16* Qb = p.Q + p.qbs * b + h * D;
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
 
   // experiment ($DTP_ATTN_SKEW=n): co-resident workgroups start in lockstep and run equal-length phases, so the waves of a SIMD ask
   // for the matrix pipe (and then for the VALU) all at once; delaying every other workgroup by n * 64 cycles de-phases them
-  if (p.skew > 0 && (blockIdx.x & 1)) {
+  if (p.skew > 0 && (qblk & 1)) {
     for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(1);
   }
   const char* const kfrag0 = Kl + lq * KROW + hf * 16;  // this lane's K / V^T fragment rows (buffer 0)
@@ -343,10 +342,7 @@ int dtp_launch_attention(const AttnParams& pin, hipStream_t s) {
     dtp_set_error("attention: D=%d ldq=%d ldk=%d ldv=%d ldo=%d unsupported", p.D, p.ldq, p.ldk, p.ldv, p.ldo);
     return DTP_ERR_ARG;
   }
-  static const bool hb_env = [] { const char* e = getenv("DTP_ATTN_HBMAJOR"); return !(e && e[0] == '0'); }();
-  p.hb_major = hb_env && ((p.H * p.B) % 8) == 0 && (p.Sq + 127) / 128 >= 8 ? 1 : 0;
   dim3 grid((p.Sq + 127) / 128, p.H, p.B), block(256);
-  if (p.hb_major) grid = dim3(p.H * p.B, (p.Sq + 127) / 128, 1);
   static const int cus = [] {
     int dev = 0;
     hipDeviceProp_t prop;

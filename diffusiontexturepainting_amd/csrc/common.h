@@ -221,7 +221,6 @@ struct AttnParams {
   long long qbs, kbs, vbs, obs; // batch strides (elements)
   float scale;
   int prio;  // $DTP_ATTN_PRIO: raise the wave priority around the MFMA clusters
-  int hb_major;  // set by the launcher: grid.x = head x batch (all query blocks of a head behind one XCD's L2)
   int skew;  // experiment ($DTP_ATTN_SKEW): start delay of every other workgroup, in units of 64 cycles
 };
 int dtp_launch_attention(const AttnParams& p, hipStream_t s);
