@@ -92,12 +92,10 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
   }
   if (tile >= 20 && tile < 32) { p.splits = 1; p.kb_per_split = p.nkb; }  // the wide and fp8 tiles are unsplit
   if ((tile >= 24 && tile < 32) != (p.W8 != nullptr)) { dtp_set_error("gemm: tiles 24..27 and W8 go together"); return DTP_ERR_ARG; }
-  if (tile >= 12 && tile < 16) {  // halo-tiled 3x3 conv: split-K counts 64-channel blocks
+  if (dtp_is_halo_tile(tile)) {  // halo-tiled 3x3 conv: split-K counts 64-channel blocks
     if (!d->Wcb) { dtp_set_error("conv_halo: Wcb missing"); return DTP_ERR_ARG; }
     p.W = (const f16*)d->Wcb;
-    const int sp = d->splits >= 1 ? d->splits : 1;
-    p.kb_per_split = (p.nkb + sp - 1) / sp;
-    p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
+    dtp_split_k(p.nkb, tile, d->splits >= 1 ? d->splits : 1, &p.kb_per_split, &p.splits);
   }
   rc = ops_ws(dtp_gemm_workspace_bytes(p));
   if (rc) return rc;
@@ -107,7 +105,7 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
     (void)dtp_gemm_tile_dims(tile, &bm, &bn, &ns);
     d->st_parts_out = p.splits > 1 ? 1 : (p.N + bn - 1) / bn;
   }
-  if (tile >= 12 && tile < 16) return dtp_launch_conv_halo(p, tile - 12, (hipStream_t)s);
+  if (dtp_is_halo_tile(tile)) return dtp_launch_conv_halo(p, dtp_halo_variant(tile), (hipStream_t)s);
   return dtp_launch_gemm(p, tile, (hipStream_t)s);
 }
 

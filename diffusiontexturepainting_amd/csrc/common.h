@@ -30,10 +30,12 @@ static __device__ __forceinline__ f16x8 lds_read16(uint32_t addr) {
 // s_waitcnt lgkmcnt(N) that the NF fragments "pass through", so their consumers cannot be scheduled above the wait
 template <int N, int NF>
 static __device__ __forceinline__ void wait_lds_frags(f16x8 (&f)[NF]) {
-  static_assert(NF == 2 || NF == 3 || NF == 4 || NF == 6 || NF == 7 || NF == 8, "fragment count");
+  static_assert(NF == 2 || NF == 3 || NF == 4 || NF == 5 || NF == 6 || NF == 7 || NF == 8, "fragment count");
   if constexpr (NF == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(N));
   else if constexpr (NF == 3) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : "n"(N));
   else if constexpr (NF == 4) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N));
+  else if constexpr (NF == 5)
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]) : "n"(N));
   else if constexpr (NF == 6)
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(N));
   else if constexpr (NF == 7)
@@ -281,7 +283,20 @@ bool dtp_gemm_wide_supported(const GemmParams& p, int variant);
 int dtp_launch_gemm_wide(const GemmParams& p, int variant, hipStream_t s);
 void dtp_gemm_wide_init();
 // conv_halo.hip: variant 0..3 = (8x16|8x8 pixel tile) x (64|128 output channels); kb_per_split counts 64-channel blocks
+inline bool dtp_is_halo_tile(int tile) { return (tile >= 12 && tile < 16) || tile == 48 || tile == 49; }
+inline int dtp_halo_variant(int tile) { return tile >= 48 ? tile - 44 : tile - 12; }
+constexpr int DTP_TILE_IDS = 50;  // tile ids are 0 .. DTP_TILE_IDS - 1
+// Split-K of a problem of nkb 64-wide k-blocks into (at most) sp slices.  conv_halo_kernel unrolls the nine taps of a channel block:
+// its slices are multiples of 9 k-blocks (the 9 * Cin/64 conv blocks come first, so no channel block is cut).
+inline void dtp_split_k(int nkb, int tile, int sp, int* kb_per_split, int* splits) {
+  if (sp < 1) sp = 1;
+  int kbps = (nkb + sp - 1) / sp;
+  if (dtp_is_halo_tile(tile) && sp > 1) kbps = (((nkb + 8) / 9 + sp - 1) / sp) * 9;
+  *kb_per_split = kbps;
+  *splits = (nkb + kbps - 1) / kbps;
+}
 bool dtp_conv_halo_supported(const GemmParams& p);
+bool dtp_conv_halo3_supported(const GemmParams& p);  // variants 4 / 5 (tile ids 48 / 49): three images per workgroup
 int dtp_launch_conv_halo(const GemmParams& p, int variant, hipStream_t s);
 void dtp_conv_halo_init();
 int dtp_launch_pack_conv_weight_cb(const float* w, f16* out, int Cout, int Cin, int ldw, hipStream_t s);

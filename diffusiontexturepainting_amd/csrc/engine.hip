@@ -459,7 +459,7 @@ static void tune_read_file(Ctx* c, const char* path) {
   char key[256];
   int tile, splits;
   while (fscanf(f, "%255s %d %d", key, &tile, &splits) == 3)
-    if (tile >= 0 && tile < 48 && splits >= 1 && splits <= 64) c->tuned[key] = std::make_pair(tile, splits);  // shape-level checks: tune_entry_valid()
+    if (tile >= 0 && tile < DTP_TILE_IDS && splits >= 1 && splits <= 64) c->tuned[key] = std::make_pair(tile, splits);  // shape-level checks: tune_entry_valid()
   fclose(f);
 }
 
@@ -480,8 +480,13 @@ void tune_cache_load(Ctx* c) {
 // not 128 wide, or a split LayerNorm-fold would otherwise reach the kernels.
 static bool tune_entry_valid(const GemmParams& p, int tile, int sp) {
   if (sp < 1 || sp > p.nkb) return false;
-  const bool halo = tile >= 12 && tile < 16;
-  if (halo) return p.Wcb && dtp_conv_halo_supported(p) && p.batch <= 1;
+  {
+    int kbps, n;
+    dtp_split_k(p.nkb, tile, sp, &kbps, &n);
+    if (n != sp) return false;  // not a factor this tile can realise
+  }
+  const bool halo = dtp_is_halo_tile(tile);
+  if (halo) return p.Wcb && (tile >= 48 ? dtp_conv_halo3_supported(p) : dtp_conv_halo_supported(p)) && p.batch <= 1;
   if (p.flags & GF_GNAPPLY) return false;  // only the halo kernel normalises its staged input
   int bm = 0, bn = 0, ns = 0;
   if (!dtp_gemm_tile_dims(tile, &bm, &bn, &ns)) return false;
@@ -512,8 +517,8 @@ void tune_cache_save(Ctx* c) {
 // with every tile variant x split-K factor on the real buffers and the fastest pair is kept.
 static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   char key[200];
-  // "k6|": bump when tile ids or pipelines change, so that a persisted table written by an older build is ignored
-  int kl = snprintf(key, sizeof(key), "k6|%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
+  // "k7|": bump when tile ids or pipelines change, so that a persisted table written by an older build is ignored
+  int kl = snprintf(key, sizeof(key), "k7|%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
                     p.stride, p.lda, p.ldc, p.ldw, p.st_parts, p.Cin2, p.lda2);
   if (p.batch > 1) kl += snprintf(key + kl, sizeof(key) - kl, ",b%d", p.batch);
   if (p.W8) snprintf(key + kl, sizeof(key) - kl, ",f8");
@@ -539,10 +544,9 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     auto time_cfg = [&](int tile, int sp, int reps, float* out_ms) -> int {
       *out_ms = -1.f;
       GemmParams q = p;
-      const bool halo = tile >= 12 && tile < 16;
+      const bool halo = dtp_is_halo_tile(tile);
       if (halo) q.W = p.Wcb;
-      q.kb_per_split = (p.nkb + sp - 1) / sp;
-      q.splits = (p.nkb + q.kb_per_split - 1) / q.kb_per_split;
+      dtp_split_k(p.nkb, tile, sp, &q.kb_per_split, &q.splits);
       if (q.splits != sp && sp > 1) return DTP_OK;
       const size_t need = dtp_gemm_workspace_bytes(q);
       if (need > ((size_t)512 << 20)) return DTP_OK;
@@ -555,7 +559,7 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
         RC(dtp_launch_touch(q.A, a_bytes, (float*)c->tune_thrash, 0));
         if (q.R) RC(dtp_launch_touch(q.R, (size_t)q.M * q.ldr * 2, (float*)c->tune_thrash, 0));
         HIP_CHECK(hipEventRecord(c->tune_ev[0], 0));
-        if (halo) RC(dtp_launch_conv_halo(q, tile - 12, 0)); else RC(dtp_launch_gemm(q, tile, 0));
+        if (halo) RC(dtp_launch_conv_halo(q, dtp_halo_variant(tile), 0)); else RC(dtp_launch_gemm(q, tile, 0));
         HIP_CHECK(hipEventRecord(c->tune_ev[1], 0));
         HIP_CHECK(hipEventSynchronize(c->tune_ev[1]));
         float t = 0.f;
@@ -615,6 +619,15 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
           if (ms >= 0.f) cands.push_back({ms, 12 + v, sp});
         }
       }
+      // three images per workgroup: the small maps of a batch-1 stamp, where the weight slices are most of the LDS fill
+      static const bool no_halo3 = [] { const char* e = getenv("DTP_NO_HALO3"); return e && e[0] && e[0] != '0'; }();
+      for (int tile = 48; tile < 50 && !no_halo3 && p.Hi * p.Wi <= 256 && dtp_conv_halo3_supported(p); ++tile)
+        for (int sp : cand_splits) {
+          if (sp > 1 && p.nkb / sp < 9) break;
+          float ms;
+          RC(time_cfg(tile, sp, 5, &ms));
+          if (ms >= 0.f) cands.push_back({ms, tile, sp});
+        }
     }
     // second round: the three fastest candidates are usually within the measurement noise of each other -- time them again,
     // longer, and keep the minimum over both rounds
@@ -629,15 +642,14 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     it = c->tuned.emplace(key, std::make_pair(bt, bs)).first;
     if (getenv("DTP_TUNE_REPORT")) {  // how much of the chosen configuration's time is the cold operands?
       GemmParams q = p;
-      if (bt >= 12 && bt < 16) q.W = p.Wcb;
-      q.kb_per_split = (p.nkb + bs - 1) / bs;
-      q.splits = (p.nkb + q.kb_per_split - 1) / q.kb_per_split;
+      if (dtp_is_halo_tile(bt)) q.W = p.Wcb;
+      dtp_split_k(p.nkb, bt, bs, &q.kb_per_split, &q.splits);
       q.part = c->ws;
       q.zero = c->zero;
       float hot = 1e30f;
       for (int rep = 0; rep < 4; ++rep) {
         HIP_CHECK(hipEventRecord(c->tune_ev[0], 0));
-        if (bt >= 12 && bt < 16) RC(dtp_launch_conv_halo(q, bt - 12, 0)); else RC(dtp_launch_gemm(q, bt, 0));
+        if (dtp_is_halo_tile(bt)) RC(dtp_launch_conv_halo(q, dtp_halo_variant(bt), 0)); else RC(dtp_launch_gemm(q, bt, 0));
         HIP_CHECK(hipEventRecord(c->tune_ev[1], 0));
         HIP_CHECK(hipEventSynchronize(c->tune_ev[1]));
         float t = 0.f;
@@ -657,8 +669,7 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     }
   }
   *tile_out = it->second.first;
-  p.kb_per_split = (p.nkb + it->second.second - 1) / it->second.second;
-  p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
+  dtp_split_k(p.nkb, it->second.first, it->second.second, &p.kb_per_split, &p.splits);
   return DTP_OK;
 }
 
@@ -667,7 +678,7 @@ static Op make_gemm_op(Ctx* c, GemmParams p, int tile, int bias_step_off) {
     GemmParams q = p;
     q.part = c->ws;
     if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;
-    if (tile >= 12 && tile < 16) { q.W = q.Wcb; return dtp_launch_conv_halo(q, tile - 12, s); }
+    if (dtp_is_halo_tile(tile)) { q.W = q.Wcb; return dtp_launch_conv_halo(q, dtp_halo_variant(tile), s); }
     return dtp_launch_gemm(q, tile, s);
   };
 }
@@ -700,7 +711,7 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
            p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? (f8tile ? " geglu fp8" : " geglu") : (f8tile ? " fp8" : ""), p.stride == 2 ? " s2" : "",
            p.batch > 1 ? (" x" + std::to_string(p.batch)).c_str() : "");
-  const int kind = tile >= 40 ? PK_LW + tile - 40 : tile >= 32 ? PK_KH2 + tile - 32 : tile >= 24 ? PK_FP8 : tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
+  const int kind = tile >= 48 ? PK_HALO3 + tile - 48 : tile >= 40 ? PK_LW + tile - 40 : tile >= 32 ? PK_KH2 + tile - 32 : tile >= 24 ? PK_FP8 : tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
   const double flops = 2.0 * nb * p.M * (double)p.N * k_alg;
   prog_push(c, prog, kind, flops, bytes, make_gemm_op(c, p, tile, bias_step_off), lab);
   if (p.splits > 1) {  // a GroupNorm pushed next may take over the reduce (Builder::gn)

@@ -296,6 +296,8 @@ HALO_CASES = [
     # B, H, W, Cin, Cout, variant(12..15), splits
     (3, 64, 64, 320, 320, 12, 1), (3, 64, 64, 320, 320, 13, 1), (2, 32, 32, 640, 640, 13, 2), (3, 16, 16, 1280, 1280, 14, 4),
     (3, 8, 8, 1280, 1280, 15, 5), (1, 24, 40, 128, 128, 12, 1), (2, 12, 20, 64, 64, 14, 1), (1, 128, 128, 128, 256, 13, 1),
+    # 48 / 49: three images per workgroup
+    (3, 8, 8, 1280, 1280, 48, 5), (3, 8, 8, 1280, 1280, 49, 1), (6, 16, 16, 1280, 1280, 49, 4), (3, 16, 16, 640, 1280, 48, 2), (3, 12, 20, 64, 192, 49, 1),
 ]
 
 
@@ -316,7 +318,8 @@ def test_conv3x3_halo_kernel(ops, case):
 
 
 @pytest.mark.parametrize("b,h,cin,cin2,cout,variant,splits", [(2, 16, 64, 128, 64, 12, 1), (3, 8, 320, 640, 320, 14, 1), (1, 16, 128, 64, 256, 13, 3),
-                                                              (3, 8, 1280, 2560, 1280, 15, 7), (2, 32, 320, 960, 320, 12, 2)])
+                                                              (3, 8, 1280, 2560, 1280, 15, 7), (2, 32, 320, 960, 320, 12, 2),
+                                                              (3, 8, 320, 640, 320, 48, 1), (3, 8, 1280, 2560, 1280, 49, 7), (6, 16, 320, 640, 640, 49, 3)])
 def test_conv3x3_halo_fused_shortcut(ops, b, h, cin, cin2, cout, variant, splits):
     """Halo kernel with the ResBlock's 1x1 shortcut appended as dense k-blocks; split-K cuts the k-block sequence anywhere."""
     t, x = rnd(b, h, h, cin, seed=44), rnd(b, h, h, cin2, seed=45)
