@@ -28,6 +28,7 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_uniform) {
                                    (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
 }
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -102,7 +103,14 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
   const int ups = (p.flags & GF_UPS2) ? 1 : 0;
   const int Hlim = p.Hi << ups, Wlim = p.Wi << ups;
 
-  const f16* a_row[AR];  // dense: row pointer (or zero page)
+  // DMA pieces are buffer loads: a per-lane 32-bit byte offset (loop constant for the dense operands), the k advance in the scalar
+  // offset, so a piece costs no vector arithmetic and no 64-bit pointer select.  A lane whose row / pixel does not exist carries
+  // OOB = 0x80000000: out of range of the 2 GiB descriptors (and still so after a k offset is added), and the DMA writes zeros for it.
+  constexpr int OOB = (int)0x80000000u;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, OOB, 0x00020000);
+  const auto rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, OOB, 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, OOB, 0x00020000);
+  int a_voff[AR];  // dense: byte offset of (row, this lane's chunk); conv: of the tap's source pixel (chunk added per k-block)
   int a_pix[AR], a_y[AR], a_x[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
@@ -114,36 +122,37 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
       a_pix[i] = b * p.Hi * p.Wi;
       a_y[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 20);
       a_x[i] = ox * p.stride - p.pad;
-      a_row[i] = nullptr;
+      a_voff[i] = OOB;
     } else {
-      a_row[i] = (m < p.M) ? p.A + (size_t)m * p.lda + kc : nullptr;
+      a_voff[i] = (m < p.M) ? (m * p.lda + kc) * 2 : OOB;
       a_pix[i] = a_y[i] = a_x[i] = 0;
     }
   }
-  const f16* w_row[WR];
+  int w_voff[WR];
 #pragma unroll
   for (int i = 0; i < WR; ++i) {  // packed weights have ceil(N/128)*128 rows: a 256-wide tile may reach past them
     const int n = n0 + i * RPR + lrow;
-    w_row[i] = (BN <= 128 || n < ((p.N + 127) & ~127)) ? p.W + (size_t)n * p.ldw + kc : nullptr;
+    w_voff[i] = (BN <= 128 || n < ((p.N + 127) & ~127)) ? (n * p.ldw + kc) * 2 : OOB;
   }
 
-  int tap = 0, cch = 0, cur_tap = -1;  // conv: current tap / channel offset of this thread's chunk; tap cached in a_row[]
+  int tap = 0, cch = 0, cur_tap = -1;  // conv: current tap / channel offset of this thread's chunk; tap cached in a_voff[]
   if constexpr (conv) {
     const int k = kb0 * 64 + kc;
     if (k < 9 * p.Cin) { tap = k / p.Cin; cch = k - tap * p.Cin; }
     else { tap = 9; cch = k - 9 * p.Cin; }  // inside the fused 1x1-shortcut tail
   }
 
-  // One k-block of DMA = prep() (conv tap bookkeeping) + AR + WR "pieces" (one global_load_lds wave-instruction each,
+  // One k-block of DMA = prep() (conv tap bookkeeping) + AR + WR "pieces" (one buffer_load ... lds wave-instruction each,
   // 1 KiB).  A piece costs the issuing wave 60-180 cycles, so the main loop spreads them between its MFMAs instead of
   // issuing them back to back in front of the MFMAs.
-  size_t a_off = 0, w_off = 0;
+  int a_lane = 0, a_soff = 0, w_soff = 0;  // per-lane (conv) / scalar byte offsets of this k-block inside the rows
+  bool a_second = false;                   // the A pieces of this k-block read A2 (wave-uniform)
   bool dense_tail = false;
   const int dense_k1 = p.K - p.Cin2;  // dense two-operand GEMM: first column read from A2
   auto prep = [&](int kb) {
     if constexpr (conv) {
-      // The tap (ky,kx) only changes every Cin/64 k-blocks: the per-row bounds test and pixel address are
-      // recomputed then and cached in a_row[]; in between only the channel offset advances.
+      // The tap (ky,kx) only changes every Cin/64 k-blocks: the per-row bounds test and pixel offset are
+      // recomputed then and cached in a_voff[]; in between only the channel offset advances.
       if (tap != cur_tap) {
         cur_tap = tap;
         if (tap < 9) {
@@ -152,17 +161,19 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
           for (int i = 0; i < AR; ++i) {
             const int iy = a_y[i] + ky, ix = a_x[i] + kx;
             const bool ok = ((unsigned)iy < (unsigned)Hlim) && ((unsigned)ix < (unsigned)Wlim);
-            a_row[i] = ok ? p.A + (size_t)(a_pix[i] + (iy >> ups) * p.Wi + (ix >> ups)) * p.lda : nullptr;
+            a_voff[i] = ok ? (a_pix[i] + (iy >> ups) * p.Wi + (ix >> ups)) * p.lda * 2 : OOB;
           }
         } else {  // dense tail: output pixel m reads row m of the shortcut input
 #pragma unroll
           for (int i = 0; i < AR; ++i) {
             const int m = m0 + i * RPR + lrow;
-            a_row[i] = (tap == 9 && p.A2 && m < p.M) ? p.A2 + (size_t)m * p.lda2 : nullptr;
+            a_voff[i] = (tap == 9 && p.A2 && m < p.M) ? m * p.lda2 * 2 : OOB;
           }
         }
       }
-      a_off = (size_t)cch;
+      // with a shortcut operand Cin is a multiple of 64 (checked by the launcher): every lane of a k-block is on the same tap
+      a_second = __builtin_amdgcn_readfirstlane(tap) >= 9;
+      a_lane = cch * 2;
       cch += 64;
       if (tap < 9) { while (cch >= p.Cin) { cch -= p.Cin; ++tap; } }
       else if (cch >= p.Cin2) { cch -= p.Cin2; ++tap; }
@@ -170,20 +181,28 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
       // dense GEMM with a second activation matrix: columns [K - Cin2, K) of the contraction come from A2 (same rows)
       if (p.A2 && !dense_tail && kb * 64 >= dense_k1) {
         dense_tail = true;
+        a_second = true;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
           const int m = m0 + i * RPR + lrow;
-          a_row[i] = (m < p.M) ? p.A2 + (size_t)m * p.lda2 + kc : nullptr;
+          a_voff[i] = (m < p.M) ? (m * p.lda2 + kc) * 2 : OOB;
         }
       }
-      a_off = (size_t)(kb * 64 - (dense_tail ? dense_k1 : 0));
+      a_soff = (kb * 64 - (dense_tail ? dense_k1 : 0)) * 2;
     }
-    w_off = (size_t)kb * 64;
+    w_soff = kb * 128;
   };
   auto piece = [&](int stage, int q) {
     char* As = smem + stage * STAGE;
-    if (q < AR) glds16(a_row[q] ? a_row[q] + a_off : p.zero, As + (q * RPR + dwave * 8) * 128);
-    else glds16((BN <= 128 || w_row[q - AR]) ? w_row[q - AR] + w_off : p.zero, As + BM * 128 + ((q - AR) * RPR + dwave * 8) * 128);
+    if (q < AR) {
+      const int vo = a_voff[q] + a_lane;  // (by value: the host pass of hipcc rejects an array element as the builtin's argument)
+      lds_ptr_t dst = (lds_ptr_t)(As + (q * RPR + dwave * 8) * 128);
+      if (a_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, dst, 16, vo, a_soff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, vo, a_soff, 0, 0);
+    } else {
+      const int vo = w_voff[q - AR];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(As + BM * 128 + ((q - AR) * RPR + dwave * 8) * 128), 16, vo, w_soff, 0, 0);
+    }
   };
   auto issue = [&](int stage, int kb) {
     prep(kb);
@@ -783,6 +802,14 @@ int dtp_launch_gemm(const GemmParams& p, int tile, hipStream_t s) {
   if (tile == 20 || tile == 21) return dtp_launch_gemm_wide(p, tile - 20, s);
   if (tile >= 24 && tile <= 28) return dtp_launch_gemm_fp8(p, tile - 24, s);
   if ((p.lda & 7) || (p.ldw & 7)) { dtp_set_error("gemm: lda/ldw must be multiples of 8"); return DTP_ERR_ARG; }
+  {  // the DMA addresses rows by 32-bit byte offsets into 2 GiB buffer descriptors
+    const size_t a_rows = (p.flags & GF_CONV3) ? (size_t)(p.M / (p.Ho * p.Wo) + 1) * p.Hi * p.Wi : (size_t)p.M;
+    const size_t lim = (size_t)1 << 31;
+    if (a_rows * p.lda * 2 >= lim || (p.A2 && (size_t)p.M * p.lda2 * 2 >= lim) || ((size_t)p.N + 256) * p.ldw * 2 >= lim) {
+      dtp_set_error("gemm: an operand of 2 GiB or more (M %d lda %d, N %d ldw %d)", p.M, p.lda, p.N, p.ldw);
+      return DTP_ERR_ARG;
+    }
+  }
   if ((p.flags & GF_CONV3) && (p.Cin & 7)) { dtp_set_error("conv: Cin must be a multiple of 8"); return DTP_ERR_ARG; }
   if (p.A2 && (p.flags & GF_CONV3) && (((9 * p.Cin) & 63) || (p.Cin2 & 63) || (p.lda2 & 7) || p.stride != 1)) {
     dtp_set_error("conv: fused shortcut tail needs stride 1 and 9*Cin, Cin2 multiples of 64");

@@ -43,16 +43,44 @@ __global__ __launch_bounds__(1024) void stream_kernel(const char* __restrict__ s
   if (sink && lane == 0 && my[0] == 123) sink[0] = 1;
 }
 
+// The same stream issued as buffer loads: the lane part of the address is a loop-constant 32-bit offset, the piece position rides in
+// the scalar offset -- no per-piece vector arithmetic at all (what conv_halo_kernel does since round 3).
 template <int D, int PPB, bool BAR>
+__global__ __launch_bounds__(1024) void stream_buf_kernel(const char* __restrict__ src, size_t foot, size_t wg_stride, int rowb, int rounds, int* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)blockIdx.x * wg_stride), 0, (int)0x80000000u, 0x00020000);
+  const int rows = (int)(foot / rowb), cols = rowb / 128;
+  char* my = smem + (size_t)wave * D * 1024;
+  int rb = wave * 8, cb = 0, slot = 0;
+  const int r = lane >> 3, ch = lane & 7;
+  const int voff = r * rowb + ((ch ^ r) << 4);
+  for (int it = 0; it < rounds; ++it) {
+#pragma unroll
+    for (int q = 0; q < PPB; ++q) {
+      wait_vmcnt<D - 1>();
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(my + slot * 1024), 16, voff, rb * rowb + cb * 128, 0, 0);
+      slot = (slot + 1 == D) ? 0 : slot + 1;
+      if (++cb == cols) { cb = 0; rb += nw * 8; if (rb + 8 > rows) rb = wave * 8; }
+    }
+    if (BAR) __builtin_amdgcn_s_barrier();
+  }
+  wait_vmcnt<0>();
+  if (sink && lane == 0 && my[0] == 123) sink[0] = 1;
+}
+
+template <int D, int PPB, bool BAR, bool BUF = false>
 static double run(const char* buf, size_t foot, size_t wg_stride, int rowb, int waves, int blocks) {
   const int rounds = 4000 / PPB;
   const size_t lds = (size_t)waves * D * 1024;
-  (void)hipFuncSetAttribute((const void*)stream_kernel<D, PPB, BAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto kern = BUF ? stream_buf_kernel<D, PPB, BAR> : stream_kernel<D, PPB, BAR>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((stream_kernel<D, PPB, BAR>), dim3(blocks), dim3(waves * 64), lds, 0, buf, foot, wg_stride, rowb, rounds, nullptr);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, 0, buf, foot, wg_stride, rowb, rounds, nullptr);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL((stream_kernel<D, PPB, BAR>), dim3(blocks), dim3(waves * 64), lds, 0, buf, foot, wg_stride, rowb, rounds, nullptr);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, 0, buf, foot, wg_stride, rowb, rounds, nullptr);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double bytes = (double)blocks * waves * rounds * PPB * 1024.0;
@@ -80,6 +108,19 @@ int main() {
                r8, f(r8), r16, f(r16), r32, f(r32), b8, f(b8));
       }
     }
+  // buffer-load form of the same pieces (scalar piece offset, no vector address arithmetic per piece)
+  for (const Src& s : srcs) {
+    if (s.stride == 0 && s.foot > (1 << 20)) continue;
+    const int rowb = 2048;
+    if (s.foot % rowb) continue;
+    printf("%-34s row stride %5d B | buffer_load ... lds: TB/s chip (B/clk/CU) by waves, D4 / D8 | global_load_lds D4 / D8\n", s.name, rowb);
+    for (int waves : {1, 2, 4, 8, 16}) {
+      double b4 = run<4, 4, false, true>(buf, s.foot, s.stride, rowb, waves, 256), b8 = run<8, 4, false, true>(buf, s.foot, s.stride, rowb, waves, 256);
+      double g4 = run<4, 4, false>(buf, s.foot, s.stride, rowb, waves, 256), g8 = run<8, 4, false>(buf, s.foot, s.stride, rowb, waves, 256);
+      auto f = [](double t) { return t * 1e12 / 256 / 2.4e9; };
+      printf("  %2d waves: %5.2f (%4.1f)  %5.2f (%4.1f) | %5.2f (%4.1f)  %5.2f (%4.1f)\n", waves, b4, f(b4), b8, f(b8), g4, f(g4), g8, f(g8));
+    }
+  }
   // 2 and 4 workgroups per CU of 4 waves (co-residency instead of waves)
   for (int blocks : {512, 1024}) {
     double r = run<8, 4, false>(buf, 64 << 10, 64 << 10, 2560, 4, blocks);
