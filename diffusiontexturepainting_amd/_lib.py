@@ -32,7 +32,8 @@ PROF_KINDS = [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 
      "gemm_kernel<128, 256, 3>", "gemm_wide_kernel<256, 256>", "gemm_wide_kernel<256, 320>", "gemm_fp8_kernel"] + \
     [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 4}, 2>" for i in range(8)] + \
     [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, 3, 1, {(4, 8)[i // 4]}>" for i in range(8)] + \
-    ["xattn_kernel (cross-attention GEMM pair)", "conv_halo_kernel<8, 8, 64, 3 images>", "conv_halo_kernel<8, 8, 128, 3 images>"]
+    ["xattn_kernel (cross-attention GEMM pair)", "conv_halo_kernel<8, 8, 64, 3 images>", "conv_halo_kernel<8, 8, 128, 3 images>",
+     "lnlin_kernel (activation-stationary LayerNorm-folded Linear / GEGLU)"]
 
 
 class GemmDesc(C.Structure):

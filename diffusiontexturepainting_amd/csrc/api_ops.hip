@@ -64,7 +64,7 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
   int rc = ops_init();
   if (rc) return rc;
   static bool halo_init = false;
-  if (!halo_init) { dtp_conv_halo_init(); dtp_gemm_wide_init(); halo_init = true; }
+  if (!halo_init) { dtp_conv_halo_init(); dtp_gemm_wide_init(); dtp_lnlin_init(); halo_init = true; }
   GemmParams p = {};
   p.A = (const f16*)d->A; p.W = (const f16*)d->W; p.C = d->C; p.bias = d->bias; p.R = (const f16*)d->R;
   p.zero = g_ops.zero;
@@ -90,7 +90,7 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
     p.kb_per_split = (p.nkb + d->splits - 1) / d->splits;
     p.splits = (p.nkb + p.kb_per_split - 1) / p.kb_per_split;
   }
-  if (tile >= 20 && tile < 32) { p.splits = 1; p.kb_per_split = p.nkb; }  // the wide and fp8 tiles are unsplit
+  if ((tile >= 20 && tile < 32) || tile == DTP_TILE_LNLIN) { p.splits = 1; p.kb_per_split = p.nkb; }  // the wide, fp8 and lnlin tiles do not split K
   if ((tile >= 24 && tile < 32) != (p.W8 != nullptr)) { dtp_set_error("gemm: tiles 24..27 and W8 go together"); return DTP_ERR_ARG; }
   if (dtp_is_halo_tile(tile)) {  // halo-tiled 3x3 conv: split-K counts 64-channel blocks
     if (!d->Wcb) { dtp_set_error("conv_halo: Wcb missing"); return DTP_ERR_ARG; }
@@ -105,6 +105,7 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
     (void)dtp_gemm_tile_dims(tile, &bm, &bn, &ns);
     d->st_parts_out = p.splits > 1 ? 1 : (p.N + bn - 1) / bn;
   }
+  if (tile == DTP_TILE_LNLIN) return dtp_launch_lnlin(p, d->splits >= 1 ? d->splits : 4, (hipStream_t)s);
   if (dtp_is_halo_tile(tile)) return dtp_launch_conv_halo(p, dtp_halo_variant(tile), (hipStream_t)s);
   return dtp_launch_gemm(p, tile, (hipStream_t)s);
 }

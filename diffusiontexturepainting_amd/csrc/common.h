@@ -144,6 +144,7 @@ struct GemmParams {
   int nkb;           // number of 64-wide k-blocks in total
   int splits;        // grid.z
   int kb_per_split;
+  int col_ranges;    // tile DTP_TILE_LNLIN only: column ranges per row block (set by the tuner / caller)
   int Hi, Wi, Ho, Wo, Cin, stride, pad;  // CONV3 geometry (Hi/Wi are the stored input dims)
   const f16* A2;     // CONV3: a 10th, dense "tap" appended to K -- the ResBlock's 1x1 shortcut conv, read from the block input
   int lda2, Cin2;    // [M][lda2] (Cin2 channels, multiple of 64); dense GEMM: a second activation matrix supplying the LAST Cin2
@@ -285,16 +286,22 @@ void dtp_gemm_wide_init();
 // conv_halo.hip: variant 0..3 = (8x16|8x8 pixel tile) x (64|128 output channels); kb_per_split counts 64-channel blocks
 inline bool dtp_is_halo_tile(int tile) { return (tile >= 12 && tile < 16) || tile == 48 || tile == 49; }
 inline int dtp_halo_variant(int tile) { return tile >= 48 ? tile - 44 : tile - 12; }
-constexpr int DTP_TILE_IDS = 50;  // tile ids are 0 .. DTP_TILE_IDS - 1
+constexpr int DTP_TILE_LNLIN = 50;  // lnlin_kernel (lnlin.hip): the "splits" of a tune entry are its column ranges, K is not split
+constexpr int DTP_TILE_IDS = 51;    // tile ids are 0 .. DTP_TILE_IDS - 1
 // Split-K of a problem of nkb 64-wide k-blocks into (at most) sp slices.  conv_halo_kernel unrolls the nine taps of a channel block:
 // its slices are multiples of 9 k-blocks (the 9 * Cin/64 conv blocks come first, so no channel block is cut).
 inline void dtp_split_k(int nkb, int tile, int sp, int* kb_per_split, int* splits) {
   if (sp < 1) sp = 1;
+  if (tile == DTP_TILE_LNLIN) { *kb_per_split = nkb; *splits = 1; return; }
   int kbps = (nkb + sp - 1) / sp;
   if (dtp_is_halo_tile(tile) && sp > 1) kbps = (((nkb + 8) / 9 + sp - 1) / sp) * 9;
   *kb_per_split = kbps;
   *splits = (nkb + kbps - 1) / kbps;
 }
+// lnlin.hip: activation-stationary LayerNorm-folded Linear (+ GEGLU) for K = 320 / 640; nsplit = column ranges per 128-row block
+bool dtp_lnlin_supported(const GemmParams& p, int nsplit);
+int dtp_launch_lnlin(const GemmParams& p, int nsplit, hipStream_t s);
+void dtp_lnlin_init();
 bool dtp_conv_halo_supported(const GemmParams& p);
 bool dtp_conv_halo3_supported(const GemmParams& p);  // variants 4 / 5 (tile ids 48 / 49): three images per workgroup
 int dtp_launch_conv_halo(const GemmParams& p, int variant, hipStream_t s);

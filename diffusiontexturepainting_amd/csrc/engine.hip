@@ -479,12 +479,13 @@ void tune_cache_load(Ctx* c) {
 // different packing) or hand-edited: a halo tile without the channel-block-major packing, a GEGLU problem on a tile that is
 // not 128 wide, or a split LayerNorm-fold would otherwise reach the kernels.
 static bool tune_entry_valid(const GemmParams& p, int tile, int sp) {
-  if (sp < 1 || sp > p.nkb) return false;
-  {
+  if (sp < 1 || (sp > p.nkb && tile != DTP_TILE_LNLIN)) return false;
+  if (tile != DTP_TILE_LNLIN) {
     int kbps, n;
     dtp_split_k(p.nkb, tile, sp, &kbps, &n);
     if (n != sp) return false;  // not a factor this tile can realise
   }
+  if (tile == DTP_TILE_LNLIN) return dtp_lnlin_supported(p, sp);
   const bool halo = dtp_is_halo_tile(tile);
   if (halo) return p.Wcb && (tile >= 48 ? dtp_conv_halo3_supported(p) : dtp_conv_halo_supported(p)) && p.batch <= 1;
   if (p.flags & GF_GNAPPLY) return false;  // only the halo kernel normalises its staged input
@@ -517,8 +518,8 @@ void tune_cache_save(Ctx* c) {
 // with every tile variant x split-K factor on the real buffers and the fastest pair is kept.
 static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   char key[200];
-  // "k7|": bump when tile ids or pipelines change, so that a persisted table written by an older build is ignored
-  int kl = snprintf(key, sizeof(key), "k7|%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
+  // "k8|": bump when tile ids or pipelines change, so that a persisted table written by an older build is ignored
+  int kl = snprintf(key, sizeof(key), "k8|%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
                     p.stride, p.lda, p.ldc, p.ldw, p.st_parts, p.Cin2, p.lda2);
   if (p.batch > 1) kl += snprintf(key + kl, sizeof(key) - kl, ",b%d", p.batch);
   if (p.W8) snprintf(key + kl, sizeof(key) - kl, ",f8");
@@ -547,7 +548,8 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
       const bool halo = dtp_is_halo_tile(tile);
       if (halo) q.W = p.Wcb;
       dtp_split_k(p.nkb, tile, sp, &q.kb_per_split, &q.splits);
-      if (q.splits != sp && sp > 1) return DTP_OK;
+      if (tile == DTP_TILE_LNLIN) q.col_ranges = sp;
+      else if (q.splits != sp && sp > 1) return DTP_OK;
       const size_t need = dtp_gemm_workspace_bytes(q);
       if (need > ((size_t)512 << 20)) return DTP_OK;
       if (need > c->ws_bytes) { c->ws_need = std::max(c->ws_need, need); RC(ensure_ws(c)); }
@@ -559,7 +561,8 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
         RC(dtp_launch_touch(q.A, a_bytes, (float*)c->tune_thrash, 0));
         if (q.R) RC(dtp_launch_touch(q.R, (size_t)q.M * q.ldr * 2, (float*)c->tune_thrash, 0));
         HIP_CHECK(hipEventRecord(c->tune_ev[0], 0));
-        if (halo) RC(dtp_launch_conv_halo(q, dtp_halo_variant(tile), 0)); else RC(dtp_launch_gemm(q, tile, 0));
+        if (tile == DTP_TILE_LNLIN) RC(dtp_launch_lnlin(q, sp, 0));
+        else if (halo) RC(dtp_launch_conv_halo(q, dtp_halo_variant(tile), 0)); else RC(dtp_launch_gemm(q, tile, 0));
         HIP_CHECK(hipEventRecord(c->tune_ev[1], 0));
         HIP_CHECK(hipEventSynchronize(c->tune_ev[1]));
         float t = 0.f;
@@ -609,6 +612,16 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
         if (ms >= 0.f) cands.push_back({ms, tile, sp});
       }
     }
+    {  // the activation-stationary kernel of the short LayerNorm-folded contractions: column ranges per 128-row block
+      static const bool no_lnlin = [] { const char* e = getenv("DTP_NO_LNLIN"); return e && e[0] && e[0] != '0'; }();
+      static const int ranges[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 40};
+      for (int sp : ranges) {
+        if (no_lnlin || !dtp_lnlin_supported(p, sp)) continue;
+        float ms;
+        RC(time_cfg(DTP_TILE_LNLIN, sp, 5, &ms));
+        if (ms >= 0.f) cands.push_back({ms, DTP_TILE_LNLIN, sp});
+      }
+    }
     if (p.Wcb && dtp_conv_halo_supported(p)) {
       for (int v = 0; v < 4; ++v) {
         if ((v >= 2) != (p.Hi * p.Wi <= 256)) continue;  // 8x8 pixel tiles for small feature maps, 8x16 otherwise
@@ -644,12 +657,14 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
       GemmParams q = p;
       if (dtp_is_halo_tile(bt)) q.W = p.Wcb;
       dtp_split_k(p.nkb, bt, bs, &q.kb_per_split, &q.splits);
+      if (bt == DTP_TILE_LNLIN) q.col_ranges = bs;
       q.part = c->ws;
       q.zero = c->zero;
       float hot = 1e30f;
       for (int rep = 0; rep < 4; ++rep) {
         HIP_CHECK(hipEventRecord(c->tune_ev[0], 0));
-        if (dtp_is_halo_tile(bt)) RC(dtp_launch_conv_halo(q, dtp_halo_variant(bt), 0)); else RC(dtp_launch_gemm(q, bt, 0));
+        if (bt == DTP_TILE_LNLIN) RC(dtp_launch_lnlin(q, bs, 0));
+        else if (dtp_is_halo_tile(bt)) RC(dtp_launch_conv_halo(q, dtp_halo_variant(bt), 0)); else RC(dtp_launch_gemm(q, bt, 0));
         HIP_CHECK(hipEventRecord(c->tune_ev[1], 0));
         HIP_CHECK(hipEventSynchronize(c->tune_ev[1]));
         float t = 0.f;
@@ -670,6 +685,7 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   }
   *tile_out = it->second.first;
   dtp_split_k(p.nkb, it->second.first, it->second.second, &p.kb_per_split, &p.splits);
+  if (it->second.first == DTP_TILE_LNLIN) p.col_ranges = it->second.second;
   return DTP_OK;
 }
 
@@ -678,6 +694,7 @@ static Op make_gemm_op(Ctx* c, GemmParams p, int tile, int bias_step_off) {
     GemmParams q = p;
     q.part = c->ws;
     if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;
+    if (tile == DTP_TILE_LNLIN) return dtp_launch_lnlin(q, q.col_ranges, s);
     if (dtp_is_halo_tile(tile)) { q.W = q.Wcb; return dtp_launch_conv_halo(q, dtp_halo_variant(tile), s); }
     return dtp_launch_gemm(q, tile, s);
   };
@@ -709,9 +726,9 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   char lab[160];
   const bool f8tile = tile >= 24 && tile < 32;  // an fp8 problem may have kept an fp16 tile (tune_gemm)
   snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
-           p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? (f8tile ? " geglu fp8" : " geglu") : (f8tile ? " fp8" : ""), p.stride == 2 ? " s2" : "",
+           tile == DTP_TILE_LNLIN ? p.col_ranges : p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? (f8tile ? " geglu fp8" : " geglu") : (f8tile ? " fp8" : ""), p.stride == 2 ? " s2" : "",
            p.batch > 1 ? (" x" + std::to_string(p.batch)).c_str() : "");
-  const int kind = tile >= 48 ? PK_HALO3 + tile - 48 : tile >= 40 ? PK_LW + tile - 40 : tile >= 32 ? PK_KH2 + tile - 32 : tile >= 24 ? PK_FP8 : tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
+  const int kind = tile == DTP_TILE_LNLIN ? PK_LNLIN : tile >= 48 ? PK_HALO3 + tile - 48 : tile >= 40 ? PK_LW + tile - 40 : tile >= 32 ? PK_KH2 + tile - 32 : tile >= 24 ? PK_FP8 : tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
   const double flops = 2.0 * nb * p.M * (double)p.N * k_alg;
   prog_push(c, prog, kind, flops, bytes, make_gemm_op(c, p, tile, bias_step_off), lab);
   if (p.splits > 1) {  // a GroupNorm pushed next may take over the reduce (Builder::gn)

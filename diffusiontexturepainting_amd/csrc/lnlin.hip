@@ -1,0 +1,306 @@
+// LayerNorm-folded Linear (+ GEGLU) for the short contractions of UNet levels 0-1 (K = C = 320 / 640): activation-stationary.
+//
+// The transformer blocks' q/k/v projection and FF1 (GEGLU) read a LayerNorm'd [M, C] activation with C = 320 or 640: 5-10 k-blocks.
+// gemm_kernel spends such a launch on its per-tile fixed costs -- ring prologue, epilogue, tail -- not on MFMAs (M = 12288,
+// N = 2560: 28 us at K = 64, 47 us at K = 320, against 12 us of matrix-core time).  Here a workgroup keeps its 128 activation rows
+// in REGISTERS for its whole life (each wave: 32 rows x K as 32x32x16 B-operand fragments, 80 / 160 VGPRs, loaded once) and streams weight
+// rows past them: 32 output columns x 320 k per "unit" (20 KB) through a 3-deep LDS ring, one barrier and 20 MFMAs per wave and
+// unit.  There is no per-tile prologue any more -- the pipeline never drains between output chunks -- and the LayerNorm statistics
+// come for free from the resident fragments (v_dot2 over the registers), so no statistics pass and no producer-side partials.
+//
+// out[m][n] = rstd[m] * (sum_k A[m][k] W'[n][k] - mean[m] * lns[n]) + bias[n]        (GF_LNFOLD, common.h), and with GF_GEGLU
+// out[m][f] = a * gelu(g) over the [a(64) | g(64)] row packing of every 128 weight rows (same packing as gemm_kernel).
+// MFMA operand order as in gemm_kernel: acc[n][m], lane = (m = lane & 31, half = lane >> 5), register r <-> n = 8*(r/4) + 4*half + r%4:
+// the row statistics are per-LANE constants in the epilogue.  Output leaves through a wave-private LDS transpose (64-byte rows).
+#include <stdlib.h>
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ f16x8 lds_read16_off(uint32_t addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+constexpr int UNIT_BYTES = 5 * 32 * 128;     // 32 weight rows x 320 k: five swizzled [32][64] k-block images
+constexpr int STG_LD = 80;                   // bytes per staged output row (32 f16 + pad)
+constexpr int STG_BYTES = 32 * STG_LD;       // per wave
+constexpr int MAX_CHUNKS = 16;               // output chunks (32 columns; GEGLU: a/g pairs) per workgroup: sizes the vector table
+constexpr int VEC_BYTES = MAX_CHUNKS * 4 * 32 * 4;  // [chunk][la | ba | lg | bg][32] floats
+constexpr int LNLIN_LDS = 3 * UNIT_BYTES + 4 * STG_BYTES + VEC_BYTES;
+
+// KU: K / 320.  GEGLU: chunk = a/g row pair.  p.splits = column ranges (workgroups per 128-row block).
+template <int KU, bool GEGLU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void lnlin_kernel(const GemmParams p) {  // two workgroups per CU: <= 256 registers
+  constexpr int K = KU * 320, NKB = K / 64, KST = K / 16;  // k-blocks, k-steps of the whole contraction
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ring = smem;
+  char* const stg_all = smem + 3 * UNIT_BYTES;
+  float* const vecs = (float*)(smem + 3 * UNIT_BYTES + 4 * STG_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mrow = lane & 31, half = lane >> 5;
+
+  // workgroups of one row block share an XCD (block b runs on XCD b % 8): the block's activations are fetched into one L2
+  const int nsplit = p.splits;
+  const int rblocks = (p.M + 127) >> 7;
+  const int b = blockIdx.x;
+  const int split = (b >> 3) % nsplit;
+  const int rb = (b & 7) + 8 * (b / (8 * nsplit));
+  if (rb >= rblocks) return;
+  const int m0 = rb * 128;
+  const int nchunks_all = GEGLU ? (p.N >> 6) : (p.N >> 5);  // 32-column output chunks
+  const int cper = (nchunks_all + nsplit - 1) / nsplit;
+  const int c0 = split * cper, c1 = min(c0 + cper, nchunks_all);
+  if (c0 >= c1) return;
+
+  constexpr int OOB = (int)0x80000000u;
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, OOB, 0x00020000);
+
+  // ---- per-chunk vectors of this column range -> LDS (read back in the epilogues)
+  {
+    const int nch = c1 - c0;
+    for (int i = tid; i < nch * 32; i += 256) {
+      const int c = i >> 5, j = i & 31, cg = c0 + c;
+      const int ra = GEGLU ? (cg >> 1) * 128 + (cg & 1) * 32 + j : cg * 32 + j;  // packed weight row of output column j of the chunk
+      float* v = vecs + c * 128;
+      v[j] = p.lns[ra];
+      v[32 + j] = (p.flags & GF_BIAS) ? p.bias[ra] : 0.f;
+      if constexpr (GEGLU) {
+        v[64 + j] = p.lns[ra + 64];
+        v[96 + j] = (p.flags & GF_BIAS) ? p.bias[ra + 64] : 0.f;
+      }
+    }
+  }
+
+  // ---- phase 1: the 128 activation rows -> registers.  k-block kb is staged as a swizzled [128][64] image (16 KB, four 8-row pieces
+  // per wave) in slot kb % 4 of the ring + staging area, FOUR k-blocks in flight from the start -- staged one after the other the
+  // five k-blocks of C = 320 were five dependent memory round trips (~4 us per launch); fragment-shaped loads straight into the
+  // registers (one round trip) measured slower still: 32-byte row segments.  Every wave then reads the fragments of ITS 32 rows.
+  static_assert(4 * 16384 <= 3 * UNIT_BYTES + 4 * STG_BYTES, "activation staging must not reach the vector table");
+  f16x8 af[KST];
+  {
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, OOB, 0x00020000);
+    int voffA[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = i * 32 + wave * 8 + (lane >> 3);
+      const int m = m0 + r;
+      voffA[i] = (m < p.M) ? (m * p.lda + (((lane & 7) ^ ((r >> 1) & 7)) << 3)) * 2 : OOB;
+    }
+    auto issue_a = [&](int kb) {
+      char* dst = smem + (kb & 3) * 16384;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int vo = voffA[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + (i * 32 + wave * 8) * 128), 16, vo, kb * 128, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int kb = 0; kb < 4 && kb < NKB; ++kb) issue_a(kb);
+    const int row = wave * 32 + mrow;
+    const int akey = (row >> 1) & 7;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      // groups younger than kb: issued up to k-block min(kb + 2, NKB - 1) (kb = 0: up to 3)
+      constexpr int dummy = 0;
+      const int last = kb == 0 ? (NKB - 1 < 3 ? NKB - 1 : 3) : (kb + 2 < NKB - 1 ? kb + 2 : NKB - 1);
+      const int younger = last - kb;
+      if (younger >= 3) wait_vmcnt<12>(); else if (younger == 2) wait_vmcnt<8>(); else if (younger == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();  // k-block kb is complete in LDS; every wave has read k-block kb - 1: its slot takes kb + 3
+      if (kb >= 1 && kb + 3 < NKB) issue_a(kb + 3);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        af[kb * 4 + ks] = *(const f16x8*)(smem + (kb & 3) * 16384 + row * 128 + ((((ks * 2 + half) ^ akey)) << 4));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragments are in registers before anyone overwrites the slot
+      (void)dummy;
+    }
+  }
+  // LayerNorm statistics of this lane's row from the resident fragments (each half-wave holds alternate 8-element chunks)
+  float mean, rstd;
+  {
+    float s1 = 0.f, s2 = 0.f;
+    const f16x2 one2 = {(f16)1.f, (f16)1.f};
+#pragma unroll
+    for (int i = 0; i < KST; ++i) {
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const f16x2 v = {af[i][e], af[i][e + 1]};
+        s1 = __builtin_amdgcn_fdot2(v, one2, s1, false);
+        s2 = __builtin_amdgcn_fdot2(v, v, s2, false);
+      }
+    }
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    mean = s1 * (1.0f / K);
+    rstd = rsqrtf(fmaxf(s2 * (1.0f / K) - mean * mean, 0.f) + p.ln_eps);
+  }
+  __builtin_amdgcn_s_barrier();  // every wave has left the ring; the vector table is complete
+
+  // ---- phase 2: weight units.  Unit u = (chunk, k part); GEGLU chunk order a0 g0 a1 g1 ...
+  constexpr int CU_ = GEGLU ? 2 * KU : KU;  // units per output chunk
+  const int nunits = (c1 - c0) * CU_;
+  auto unit_row0 = [&](int uu) -> int {  // first packed weight row of unit uu
+    const int c = c0 + uu / CU_, s = (uu % CU_) / KU;  // s: 0 = a (or plain), 1 = g
+    return GEGLU ? (c >> 1) * 128 + (c & 1) * 32 + s * 64 : c * 32;
+  };
+  const int wr = wave * 8 + (lane >> 3);
+  const int voffW = (wr * p.ldw + (((lane & 7) ^ ((wr >> 1) & 7)) << 3)) * 2;
+  auto w_piece = [&](int uu, int kb) {  // piece kb of unit uu: rows wave*8.. of the 32, k-block kb of the unit's 320 k
+    const int soff = (unit_row0(uu) * p.ldw + (uu % KU) * 320 + kb * 64) * 2;
+    const int vo = voffW;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(ring + (uu % 3) * UNIT_BYTES + kb * 4096 + wave * 1024), 16, vo, soff, 0, 0);
+  };
+#pragma unroll
+  for (int kb = 0; kb < 5; ++kb) w_piece(0, kb);
+  if (nunits > 1) {
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) w_piece(1, kb);
+  }
+  // W fragment of k-step ks (k-block ks / 4 of the unit): rows mrow, chunk ((ks % 4) * 2 + half) ^ key
+  uint32_t xw[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) xw[s] = lds_addr(ring) + mrow * 128 + ((((s * 2 + half) ^ ((mrow >> 1) & 7))) << 4);
+  char* const stg = stg_all + wave * STG_BYTES;
+
+  f32x16 acc_a, acc_g;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc_a[r] = 0.f; acc_g[r] = 0.f; }
+
+  int slot = 0, u = 0;  // u: unit index, slot = u % 3
+  // one unit: SEL = accumulator (0: a / plain, 1: gate), PART = which 320-wide part of the contraction (both compile-time: the
+  // resident fragment of every MFMA is a fixed register)
+  auto unit = [&](auto selc, auto partc) {
+    constexpr int SEL = decltype(selc)::value, PART = decltype(partc)::value;
+    if (u + 1 < nunits) wait_vmcnt<5>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // unit u is complete in LDS; every wave has left unit u - 1: its slot takes unit u + 2
+    const bool more = u + 2 < nunits;
+    const uint32_t sb = slot * UNIT_BYTES;
+    uint32_t xs[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xs[s] = xw[s] + sb;
+    // 20 k-steps; fragments four k-steps ahead; one DMA piece of unit u + 2 every fourth MFMA
+    f16x8 wf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wf[s] = lds_read16(xs[s]);
+#define DTP_STEP(ks)                                                                                          \
+    {                                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      if constexpr ((ks) < 16) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wf[(ks) & 3]));                     \
+      else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[(ks) & 3]) : "n"(19 - (ks)));                       \
+      if constexpr (SEL == 1) acc_g = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(ks) & 3], af[PART * 20 + (ks)], acc_g, 0, 0, 0); \
+      else acc_a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(ks) & 3], af[PART * 20 + (ks)], acc_a, 0, 0, 0); \
+      if constexpr ((ks) + 4 < 20) {                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        wf[(ks) & 3] = lds_read16_off<(((ks) + 4) >> 2) * 4096>(xs[(ks) & 3]);                                \
+      }                                                                                                       \
+      if constexpr (((ks) & 3) == 1) {                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (more) w_piece(u + 2, (ks) >> 2);                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+      }                                                                                                       \
+    }
+    DTP_STEP(0) DTP_STEP(1) DTP_STEP(2) DTP_STEP(3) DTP_STEP(4) DTP_STEP(5) DTP_STEP(6) DTP_STEP(7) DTP_STEP(8) DTP_STEP(9)
+    DTP_STEP(10) DTP_STEP(11) DTP_STEP(12) DTP_STEP(13) DTP_STEP(14) DTP_STEP(15) DTP_STEP(16) DTP_STEP(17) DTP_STEP(18) DTP_STEP(19)
+#undef DTP_STEP
+    slot = (slot == 2) ? 0 : slot + 1;
+    ++u;
+  };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  for (int cl = 0; cl < c1 - c0; ++cl) {
+    unit(I0{}, I0{});
+    if constexpr (KU == 2) unit(I0{}, I1{});
+    if constexpr (GEGLU) {
+      unit(I1{}, I0{});
+      if constexpr (KU == 2) unit(I1{}, I1{});
+    }
+    {  // ---- the chunk is complete: epilogue of 32 columns x this wave's 32 rows
+      const int c = c0 + cl;
+      const float* v = vecs + cl * 128;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = 8 * q + 4 * half;
+        const f32x4 la = *(const f32x4*)(v + j), ba = *(const f32x4*)(v + 32 + j);
+        f16x4 o;
+        if constexpr (GEGLU) {
+          const f32x4 lg = *(const f32x4*)(v + 64 + j), bg = *(const f32x4*)(v + 96 + j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float av = rstd * (acc_a[4 * q + e] - mean * la[e]) + ba[e];
+            const float gv = rstd * (acc_g[4 * q + e] - mean * lg[e]) + bg[e];
+            o[e] = (f16)(av * gelu_erf(gv));
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (f16)(rstd * (acc_a[4 * q + e] - mean * la[e]) + ba[e]);
+        }
+        *(f16x4*)(stg + mrow * STG_LD + j * 2) = o;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc_a[r] = 0.f; acc_g[r] = 0.f; }
+      // wave-private transpose: 16 bytes per lane, 64-byte rows to memory
+      const int ncol = c * 32;  // first output column of the chunk
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = (lane >> 2) + 16 * rr, cc = lane & 3;
+        const int m = m0 + wave * 32 + row;
+        const f16x8 ov = *(const f16x8*)(stg + row * STG_LD + cc * 16);
+        if (m < p.M) *(f16x8*)((f16*)p.C + (size_t)m * p.ldc + ncol + cc * 8) = ov;
+      }
+    }
+  }
+}
+
+template <int KU, bool GEGLU>
+int launch(const GemmParams& p, hipStream_t s) {
+  const int rblocks = (p.M + 127) >> 7;
+  const int blocks = ((rblocks + 7) / 8) * 8 * p.splits;
+  hipLaunchKernelGGL((lnlin_kernel<KU, GEGLU>), dim3(blocks), dim3(256), LNLIN_LDS, s, p);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
+
+}  // namespace
+
+void dtp_lnlin_init() {
+  (void)hipFuncSetAttribute((const void*)lnlin_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
+  (void)hipFuncSetAttribute((const void*)lnlin_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
+  (void)hipFuncSetAttribute((const void*)lnlin_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
+  (void)hipFuncSetAttribute((const void*)lnlin_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
+}
+
+// Dense, unbatched, LayerNorm-folded (in-kernel statistics: st_in is not needed and ignored), K = 320 or 640, fp16 output, optional
+// bias / GEGLU, nothing else in the epilogue.  p.splits (1..): column ranges per 128-row block, at most MAX_CHUNKS chunks each.
+bool dtp_lnlin_supported(const GemmParams& p, int nsplit) {
+  const int allowed = GF_LNFOLD | GF_BIAS | GF_GEGLU | GF_MFAST;
+  if (!(p.flags & GF_LNFOLD) || (p.flags & ~allowed) || !p.lns || p.W8 || p.A2 || p.batch > 1) return false;
+  if (p.K != 320 && p.K != 640) return false;
+  if ((p.lda & 7) || (p.ldw & 7) || (p.ldc & 7) || p.ldw < p.K) return false;
+  const bool geglu = (p.flags & GF_GEGLU) != 0;
+  if (geglu ? (p.N & 127) : (p.N & 31)) return false;
+  if ((size_t)p.M * p.lda * 2 >= ((size_t)1 << 31) || ((size_t)p.N + 128) * p.ldw * 2 >= ((size_t)1 << 31)) return false;
+  if (nsplit < 1) return false;
+  const int nch = geglu ? (p.N >> 6) : (p.N >> 5);
+  if (nsplit > nch || (nch + nsplit - 1) / nsplit > MAX_CHUNKS) return false;
+  return true;
+}
+
+int dtp_launch_lnlin(const GemmParams& pin, int nsplit, hipStream_t s) {
+  if (!dtp_lnlin_supported(pin, nsplit)) { dtp_set_error("lnlin: unsupported problem (M %d N %d K %d flags %#x, %d column ranges)", pin.M, pin.N, pin.K, pin.flags, nsplit); return DTP_ERR_ARG; }
+  GemmParams p = pin;
+  p.splits = nsplit;
+  const bool geglu = (p.flags & GF_GEGLU) != 0;
+  int rc;
+  if (p.K == 320) rc = geglu ? launch<1, true>(p, s) : launch<1, false>(p, s);
+  else rc = geglu ? launch<2, true>(p, s) : launch<2, false>(p, s);
+  if (rc != DTP_OK) dtp_set_error("lnlin launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return rc;
+}

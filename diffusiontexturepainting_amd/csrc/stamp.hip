@@ -311,6 +311,7 @@ int dtp_finalize_weights(dtp_ctx* ctx) {
   dtp_gemm_wide_init();
   dtp_gemm_fp8_init();
   dtp_xattn_init();
+  dtp_lnlin_init();
   RC(load_unet_weights(c));
   RC(load_vae_weights(c));
   bool has_clip = false;

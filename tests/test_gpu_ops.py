@@ -121,6 +121,39 @@ def test_gemm_layernorm_fold(ops, m, c, n, tile, geglu):
     close(got, ref, tol=3e-3)
 
 
+@pytest.mark.parametrize("m,c,n,ranges,geglu,with_bias", [(300, 320, 960, 2, False, True), (12288, 320, 960, 5, False, True), (513, 640, 1920, 4, False, True),
+                                                          (129, 320, 320, 10, False, False), (513, 320, 2560, 3, True, True), (12288, 320, 2560, 5, True, True),
+                                                          (1000, 640, 5120, 8, True, True), (3072, 640, 5120, 5, True, False), (128, 320, 2560, 20, True, True)])
+def test_lnlin_activation_stationary_kernel(ops, m, c, n, ranges, geglu, with_bias):
+    """lnlin_kernel (tile id 50: activations resident in registers, weights streamed, statistics from the registers) against torch and
+    against gemm_kernel's LayerNorm fold of the same operands; `ranges` = column ranges per 128-row block (ragged last range)."""
+    from diffusiontexturepainting_amd._lib import GF_BIAS, GF_GEGLU
+    x = rnd(m, c, seed=190) * 1.7 + 0.4
+    w = rnd(n, c, seed=191, scale=c ** -0.5).float()
+    g = torch.Generator().manual_seed(192)
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    bias = 0.1 * torch.randn(n, generator=g) if with_bias else torch.zeros(n)
+    b2 = bias + w @ beta
+    ref = F.linear(F.layer_norm(x.float(), (c,), gamma, beta, 1e-5), w, bias)
+    if geglu:
+        a, gate = ref.chunk(2, dim=-1)
+        ref = a * F.gelu(gate)
+        f = torch.arange(n // 2)
+        perm = torch.empty(n, dtype=torch.long)
+        perm[f] = (f // 64) * 128 + f % 64
+        perm[n // 2 + f] = (f // 64) * 128 + 64 + f % 64
+        bp = torch.empty_like(b2)
+        bp[perm] = b2
+        b2 = bp
+    wp = ops.pack_linear((w * gamma[None]).cuda(), geglu=geglu)
+    lns = ops.rowsum(wp, c)
+    fl = (GF_GEGLU if geglu else 0) | GF_BIAS
+    got = ops.gemm(x.cuda(), wp, n, c, bias=b2.cuda(), lns=lns, tile=50, splits=ranges, flags=fl)
+    close(got, ref, tol=3e-3)
+    other = ops.gemm(x.cuda(), wp, n, c, bias=b2.cuda(), lns=lns, tile=0, flags=fl)
+    assert (got.float() - other.float()).abs().max().item() <= 2e-2 * max(1.0, other.float().abs().max().item())
+
+
 @pytest.mark.parametrize("tile", [-1, 2, 5, 8, 33, 34, 39, 41, 46])
 def test_gemm_batched_group_softmax(ops, tile):
     """Grouped GEMM (one weight matrix per batch entry) + LayerNorm fold + softmax over groups of 16 columns (14 valid):
