@@ -21,6 +21,7 @@
 
 namespace {
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ void glds16(const void* src, void* lds_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
@@ -72,7 +73,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_wide_kernel(const GemmParams
   const int ups = (p.flags & GF_UPS2) ? 1 : 0;
   const int Hlim = p.Hi << ups, Wlim = p.Wi << ups;
 
-  const f16* a_row[AR];
+  // DMA pieces are buffer loads (32-bit lane offsets, scalar k advance, out-of-range zero fill): see gemm_conv.hip
+  constexpr int OOB = (int)0x80000000u;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, OOB, 0x00020000);
+  const auto rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, OOB, 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, OOB, 0x00020000);
+  int a_voff[AR];
   int a_pix[AR], a_y[AR], a_x[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
@@ -84,23 +90,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_wide_kernel(const GemmParams
       a_pix[i] = b * p.Hi * p.Wi;
       a_y[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 20);
       a_x[i] = ox * p.stride - p.pad;
-      a_row[i] = nullptr;
+      a_voff[i] = OOB;
     } else {
-      a_row[i] = (m < p.M) ? p.A + (size_t)m * p.lda + kc : nullptr;
+      a_voff[i] = (m < p.M) ? (m * p.lda + kc) * 2 : OOB;
       a_pix[i] = a_y[i] = a_x[i] = 0;
     }
   }
   const int n_rows_packed = (p.N + 127) & ~127;  // packed weights have ceil(N/128)*128 rows
-  const f16* w_row[WR];
+  int w_voff[WR];
 #pragma unroll
   for (int i = 0; i < WR; ++i) {
     const int n = n0 + i * RPR + lrow;
-    w_row[i] = (n < n_rows_packed) ? p.W + (size_t)n * p.ldw + kc : nullptr;
+    w_voff[i] = (n < n_rows_packed) ? (n * p.ldw + kc) * 2 : OOB;
   }
 
   int tap = 0, cch = 0, cur_tap = -1;  // conv: tap / channel offset of this thread's chunk for the NEXT prep()
   if (conv) { tap = kc / p.Cin; cch = kc - tap * p.Cin; if (tap > 9) tap = 9; }
-  size_t a_off = 0, w_off = 0;
+  int a_lane = 0, a_soff = 0, w_soff = 0;  // per-lane (conv) / scalar byte offsets of this k-block inside the rows
+  bool a_second = false;                   // the A pieces of this k-block read A2 (wave-uniform)
   bool dense_tail = false;
   const int dense_k1 = p.K - p.Cin2;
   auto prep = [&](int kb) {
@@ -113,37 +120,46 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_wide_kernel(const GemmParams
           for (int i = 0; i < AR; ++i) {
             const int iy = a_y[i] + ky, ix = a_x[i] + kx;
             const bool ok = ((unsigned)iy < (unsigned)Hlim) && ((unsigned)ix < (unsigned)Wlim);
-            a_row[i] = ok ? p.A + (size_t)(a_pix[i] + (iy >> ups) * p.Wi + (ix >> ups)) * p.lda : nullptr;
+            a_voff[i] = ok ? (a_pix[i] + (iy >> ups) * p.Wi + (ix >> ups)) * p.lda * 2 : OOB;
           }
         } else {  // fused 1x1 shortcut: output pixel m reads row m of the block input
 #pragma unroll
           for (int i = 0; i < AR; ++i) {
             const int m = m0 + i * RPR + lrow;
-            a_row[i] = (tap == 9 && p.A2 && m < p.M) ? p.A2 + (size_t)m * p.lda2 : nullptr;
+            a_voff[i] = (tap == 9 && p.A2 && m < p.M) ? m * p.lda2 * 2 : OOB;
           }
         }
       }
-      a_off = (size_t)cch;
+      a_second = __builtin_amdgcn_readfirstlane(tap) >= 9;  // with a shortcut operand Cin % 64 == 0: one tap per k-block
+      a_lane = cch * 2;
       cch += 64;
       if (tap < 9) { while (cch >= p.Cin) { cch -= p.Cin; ++tap; } }
       else if (cch >= p.Cin2) { cch -= p.Cin2; ++tap; }
     } else {
       if (p.A2 && !dense_tail && kb * 64 >= dense_k1) {  // second activation matrix supplies the last Cin2 columns
         dense_tail = true;
+        a_second = true;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
           const int m = m0 + i * RPR + lrow;
-          a_row[i] = (m < p.M) ? p.A2 + (size_t)m * p.lda2 + kc : nullptr;
+          a_voff[i] = (m < p.M) ? (m * p.lda2 + kc) * 2 : OOB;
         }
       }
-      a_off = (size_t)(kb * 64 - (dense_tail ? dense_k1 : 0));
+      a_soff = (kb * 64 - (dense_tail ? dense_k1 : 0)) * 2;
     }
-    w_off = (size_t)kb * 64;
+    w_soff = kb * 128;
   };
   auto piece = [&](int stage, int q) {
     char* As = smem + stage * STAGE;
-    if (q < AR) glds16(a_row[q] ? a_row[q] + a_off : p.zero, As + (q * RPR + wave * 8) * 128);
-    else glds16(w_row[q - AR] ? w_row[q - AR] + w_off : p.zero, As + BM * 128 + ((q - AR) * RPR + wave * 8) * 128);
+    if (q < AR) {
+      const int vo = a_voff[q] + a_lane;  // (by value: the host pass of hipcc rejects an array element as the builtin's argument)
+      lds_ptr_t dst = (lds_ptr_t)(As + (q * RPR + wave * 8) * 128);
+      if (a_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, dst, 16, vo, a_soff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, vo, a_soff, 0, 0);
+    } else {
+      const int vo = w_voff[q - AR];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(As + BM * 128 + ((q - AR) * RPR + wave * 8) * 128), 16, vo, w_soff, 0, 0);
+    }
   };
 
   f32x16 acc[TN][TM];
@@ -440,6 +456,11 @@ bool dtp_gemm_wide_supported(const GemmParams& p, int variant) {
   if ((p.flags & GF_CONV3) && (p.Cin & 7)) return false;
   if (p.A2 && (p.flags & GF_CONV3) && (((9 * p.Cin) & 63) || (p.Cin2 & 63) || (p.lda2 & 7) || p.stride != 1)) return false;
   if (p.A2 && !(p.flags & GF_CONV3) && ((p.Cin2 & 63) || ((p.K - p.Cin2) & 63) || p.Cin2 <= 0 || p.Cin2 >= p.K || (p.lda2 & 7) || (p.flags & GF_LNFOLD))) return false;
+  {  // 32-bit byte offsets into 2 GiB buffer descriptors
+    const size_t a_rows = (p.flags & GF_CONV3) ? (size_t)(p.M / (p.Ho * p.Wo) + 1) * p.Hi * p.Wi : (size_t)p.M;
+    const size_t lim = (size_t)1 << 31;
+    if (a_rows * p.lda * 2 >= lim || (p.A2 && (size_t)p.M * p.lda2 * 2 >= lim) || ((size_t)p.N + 320) * p.ldw * 2 >= lim) return false;
+  }
   return p.nkb > 0 && p.M > 0 && p.N > 0 && !(p.lda & 7) && !(p.ldw & 7);
 }
 
