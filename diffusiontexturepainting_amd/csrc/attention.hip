@@ -226,9 +226,10 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
           if (kv >= p.Skv) sacc[kb][r] = NEG;
         }
     }
-    float mloc = fmaxf(fmaxf(sacc[0][0], sacc[1][0]), fmaxf(sacc[0][1], sacc[1][1]));
+    // 32 scores per lane: a chain of three-input maxima (v_max3_f32: 16 instructions; a tree of two-input maxima compiled to 41)
+    float mloc = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
-    for (int r = 2; r < 16; r += 2) mloc = fmaxf(mloc, fmaxf(fmaxf(sacc[0][r], sacc[1][r]), fmaxf(sacc[0][r + 1], sacc[1][r + 1])));
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, sacc[0][r]), sacc[1][r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
     f16x8 pf[2][2];
     float lsum = 0.f;

@@ -125,7 +125,9 @@ int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes);
  * 14 = layernorm, 15 = concat/elementwise, 16 = softmax_rows, 17-20 = conv_halo_kernel<8,16,64> / <8,16,128> / <8,8,64> /
  * <8,8,128> (halo-tiled 3x3 conv), 21-24 = gemm_kernel<256,128,2> / <256,128,3> / <128,256,2> / <128,256,3>,
  * 25-26 = gemm_wide_kernel<256,256> / <256,320> (8-wave wide tiles), 27 = gemm_fp8_kernel (all tiles),
- * 28-35 = gemm_kernel<BM,BN,NS,2> (the 8-wave twins of shapes 0..3 at 2 / 3 stages).  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
+ * 28-35 = gemm_kernel<BM,BN,NS,2> (the 8-wave twins of shapes 0..3 at 2 / 3 stages), 36-43 = gemm_kernel<BM,BN,3,1,LW> (4 / 8 loader
+ * waves), 44 = xattn_kernel (fused cross-attention GEMM pair), 45-46 = conv_halo_kernel<8,8,64|128> with three images per workgroup,
+ * 47 = lnlin_kernel (activation-stationary LayerNorm-folded Linear / GEGLU).  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
  * dtp_profile(ctx, 0) switches back to graph replay.  The nvtx/cudaEvent hooks of
  * stable_diffusion_pipeline.py:146-149,486-503 are the reference counterpart. */
 typedef struct { int kind; int launches; double ms; double flops; double bytes; } dtp_prof_row;
@@ -164,8 +166,13 @@ typedef struct {
                         20 / 21 = gemm_wide_kernel 256x256 / 256x320 (8 waves; unsplit, N % 8 == 0; 21: no GEGLU);
                         24..28 = gemm_fp8_kernel 128x128 / 128x64 / 64x64 / 64x128 / 256x256 (8 waves) (needs W8; dense, unsplit);
                         32..39 = gemm_kernel with EIGHT waves on shape (id & 3), 2 + (id - 32) / 4 stages: waves 4-7 multiply the
-                        second half of every k-block and the halves are summed through LDS (same features as ids 0..11) */
-  int splits;        /* 0 = heuristic; >=1 = forced split-K factor */
+                        second half of every k-block and the halves are summed through LDS (same features as ids 0..11);
+                        40..47 = gemm_kernel on shape (id & 3), 3 stages, with 4 (40..43) or 8 (44..47) extra DMA-only loader waves;
+                        48 / 49 = conv_halo_kernel 8x8 x (64|128) with the same pixel tile of THREE consecutive images per
+                        workgroup (image count % 3 == 0, needs Wcb);
+                        50 = lnlin_kernel: DTP_GF_LNFOLD (+ BIAS, GEGLU) with K = 320 or 640, statistics computed in-kernel
+                        (st_in ignored); `splits` = column ranges per 128-row block (default 4) */
+  int splits;        /* 0 = heuristic; >=1 = forced split-K factor (conv_halo_kernel: slices are whole 64-channel blocks) */
   const float* lns;  /* DTP_GF_LNFOLD: row sums of the packed weights (dtp_op_rowsum) */
   float ln_eps;
   const void* A2;    /* conv only: fused 1x1-shortcut tail, f16 [M][lda2] with Cin2 channels appended to K (W = [W3x3 | W1x1]) */

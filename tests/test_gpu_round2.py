@@ -378,7 +378,7 @@ def test_tune_table_roundtrip_and_tampering(tmp_path, sd, monkeypatch, capfd):
     out1 = stamp()
     table1 = cache.read_text()
     rows = [ln.split() for ln in table1.splitlines()]
-    assert len(rows) >= 20 and all(len(r) == 3 and r[0].startswith("k7|") for r in rows)
+    assert len(rows) >= 20 and all(len(r) == 3 and r[0].startswith("k8|") for r in rows)
     capfd.readouterr()
     out2 = stamp()
     assert cache.read_text() == table1          # nothing was tuned again: every saved entry was read back and accepted
