@@ -26,12 +26,14 @@ constexpr int XSTAGE = (XBM + XBN) * 128;       // one phase-1 k-block: 64 activ
 constexpr int XW2 = 2 * XBN * 128;              // the W2 tile: two k-blocks of 128 rows
 constexpr int XP = 2 * XBM * 128;               // the probability tile: two k-blocks of 64 rows
 constexpr int XSLD = XBN + 8;                   // staging row stride (f16)
-constexpr int XLDS = 2 * XSTAGE + XW2 + XP + XBM * 8;
+constexpr int XNS = 4;                          // phase-1 ring depth: three k-blocks in flight (two stages left the DMA latency of
+                                                // every one of the C/64 k-blocks exposed: ~1 us each in a 20 us launch)
+constexpr int XLDS = XNS * XSTAGE + XW2 + XP + XBM * 8;
 
 __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const ring = smem;                       // [2][XSTAGE]; reused as the fp16 staging tile of both epilogues
-  char* const w2s = smem + 2 * XSTAGE;           // [2][128][128 B]
+  char* const ring = smem;                       // [XNS][XSTAGE]; reused as the fp16 staging tile of both epilogues
+  char* const w2s = smem + XNS * XSTAGE;         // [2][128][128 B]
   char* const ps = w2s + XW2;                    // [2][64][128 B]
   float* const rowst = (float*)(ps + XP);        // [64][2] mean, rstd
 
@@ -69,7 +71,9 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
     for (int i = 0; i < 4; ++i) glds16(w1_row[i] + (size_t)kb * 64, As + XBM * 128 + (i * 32 + wave * 8) * 128);
   };
   const int nkb = p.C >> 6;
-  issue(0, 0);
+#pragma unroll
+  for (int t = 0; t < XNS - 1; ++t)
+    if (t < nkb) issue(t, t);
 
   // ---- LayerNorm-2 statistics of this tile's rows from the producer's partial sums (GF_LNFOLD of gemm_kernel)
   if (tid < XBM) {
@@ -104,13 +108,22 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
     }
   };
 
-  // ---- phase 1: S = X W1^T over K = C (double buffered)
-  for (int t = 0; t < nkb; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // k-block t (and, the first time, the W2 tile) has landed
-    __syncthreads();                                   // ... for every wave; everyone has left k-block t-1
-    if (t + 1 < nkb) issue((t + 1) & 1, t + 1);
-    const char* As = ring + (t & 1) * XSTAGE;
-    kblock(As, As + XBM * 128);
+  // ---- phase 1: S = X W1^T over K = C; XNS-deep ring, counted vmcnt (6 DMA instructions per wave and k-block; the W2 tile's 8 are
+  // older than every k-block)
+  {
+    int slot = 0, nslot = XNS - 1;
+    for (int t = 0; t < nkb; ++t) {
+      const int ahead = min(XNS - 2, nkb - 1 - t);  // younger k-blocks already issued
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                 // k-block t has landed for every wave; everyone has left k-block t-1
+      if (t + XNS - 1 < nkb) issue(nslot, t + XNS - 1);
+      const char* As = ring + slot * XSTAGE;
+      kblock(As, As + XBM * 128);
+      slot = (slot + 1 == XNS) ? 0 : slot + 1;
+      nslot = (nslot + 1 == XNS) ? 0 : nslot + 1;
+    }
   }
   __syncthreads();  // the ring is free: it becomes the staging tile
 
