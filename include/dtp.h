@@ -140,7 +140,8 @@ int dtp_profile_dump(dtp_ctx* ctx, const char* path);
  * final latents and the decoded image looks for NaN/inf (the reference asserts `not isnan` after every step with a host
  * sync each, stable_diffusion_pipeline.py:415) -- read the verdict with dtp_last_stamp_finite; "fp8_attention" / "fp8_linear"
  * (default 0): the UNet's self-attention / its transformer Linears and 1x1 convs (proj_in, q/k/v, to_out, GEGLU FFN,
- * ff.net.2 + proj_out) run on the fp8 (e4m3) MX MFMA -- BASELINE configs[4]; choose before the first stamp. */
+ * ff.net.2 + proj_out) run on the fp8 (e4m3) MX MFMA -- BASELINE configs[4]; choose before the first stamp.  Limitation: activations
+ * are cast to e4m3 with unit scale (saturation at +-448); validated with the seeded synthetic weights only. */
 int dtp_set_option(dtp_ctx* ctx, const char* name, int value);
 /* *finite = 1 if the last stamp (run with "check_finite" on) produced only finite values, 0 otherwise.  Blocks until that
  * stamp has finished; DTP_ERR_STATE if the option was off. */
