@@ -1,4 +1,4 @@
-"""The bench.py output contract (one JSON line) checked on the committed round-2 measurement, plus the helper that attaches the
+"""The bench.py output contract (one JSON line) checked on the committed round-3 measurement, plus the helper that attaches the
 PMC traffic figure.  CPU only: nothing here launches a kernel."""
 import importlib.util
 import json
@@ -15,7 +15,7 @@ def _bench():
 
 
 def test_committed_bench_line_has_every_contract_field():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_b1.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_b1.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
