@@ -33,7 +33,7 @@ PROF_KINDS = [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 
     [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 4}, 2>" for i in range(8)] + \
     [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, 3, 1, {(4, 8)[i // 4]}>" for i in range(8)] + \
     ["xattn_kernel (cross-attention GEMM pair)", "conv_halo_kernel<8, 8, 64, 3 images>", "conv_halo_kernel<8, 8, 128, 3 images>",
-     "lnlin_kernel (activation-stationary LayerNorm-folded Linear / GEGLU)"]
+     "lnlin_kernel (activation-stationary LayerNorm-folded Linear / GEGLU)", "convws_kernel<8, 8, 3 images>", "convws_kernel<16, 16>"]
 
 
 class GemmDesc(C.Structure):
@@ -47,7 +47,7 @@ class GemmDesc(C.Structure):
                 ("batch", C.c_int), ("a_bs", C.c_int64), ("w_bs", C.c_int64), ("c_bs", C.c_int64), ("r_bs", C.c_int64),
                 ("bias_bs", C.c_int), ("lns_bs", C.c_int), ("sm_valid", C.c_int),
                 ("st_out", C.c_void_p), ("st_in", C.c_void_p), ("st_parts", C.c_int), ("st_parts_out", C.c_int),
-                ("W8", C.c_void_p), ("ldw8", C.c_int), ("a_scale", C.c_float), ("w_scale", C.c_float)]
+                ("W8", C.c_void_p), ("ldw8", C.c_int), ("a_scale", C.c_float), ("w_scale", C.c_float), ("Wfr", C.c_void_p)]
 
 
 GF_BIAS, GF_BIAS_M, GF_RESID, GF_GEGLU, GF_GELU, GF_QUICKGELU, GF_OUT_F32, GF_SILU, GF_LNFOLD = 1, 2, 4, 8, 64, 128, 256, 512, 1024
@@ -88,6 +88,8 @@ SYMBOLS = {
     "dtp_op_rowsum": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "dtp_op_quantize_w8": (_i, [_vp, _i, _i, _i, _vp, _i, C.POINTER(_f), _vp]),
     "dtp_op_pack_conv_cb": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "dtp_op_pack_conv_ws": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "dtp_op_pack_conv_ws_elems": (C.c_longlong, [_i, _i, _i]),
     "dtp_op_groupnorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "dtp_op_measure_peaks": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dtp_op_reduce_groupnorm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

@@ -64,7 +64,7 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
   int rc = ops_init();
   if (rc) return rc;
   static bool halo_init = false;
-  if (!halo_init) { dtp_conv_halo_init(); dtp_gemm_wide_init(); dtp_lnlin_init(); halo_init = true; }
+  if (!halo_init) { dtp_conv_halo_init(); dtp_gemm_wide_init(); dtp_lnlin_init(); dtp_conv_ws_init(); halo_init = true; }
   GemmParams p = {};
   p.A = (const f16*)d->A; p.W = (const f16*)d->W; p.C = d->C; p.bias = d->bias; p.R = (const f16*)d->R;
   p.zero = g_ops.zero;
@@ -80,6 +80,7 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
   p.st_out = d->st_out; p.st_in = d->st_in; p.st_parts = d->st_parts;
   if (p.batch > 1) p.st_rows = p.batch * p.M;  // statistics tables are [parts][batch * M][2]
   p.W8 = (const unsigned char*)d->W8; p.ldw8 = d->ldw8; p.a_scale = d->a_scale; p.w_scale = d->w_scale;
+  p.Wfr = (const f16*)d->Wfr;
   static bool fp8_init = false;
   if (!fp8_init) { dtp_gemm_fp8_init(); fp8_init = true; }
   if (p.ldw < p.nkb * 64) { dtp_set_error("gemm: ldw=%d smaller than padded K=%d", p.ldw, p.nkb * 64); return DTP_ERR_ARG; }
@@ -97,9 +98,11 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
     p.W = (const f16*)d->Wcb;
     dtp_split_k(p.nkb, tile, d->splits >= 1 ? d->splits : 1, &p.kb_per_split, &p.splits);
   }
+  if (dtp_is_ws_tile(tile)) dtp_split_k(p.nkb, tile, d->splits >= 1 ? d->splits : 1, &p.kb_per_split, &p.splits);
   rc = ops_ws(dtp_gemm_workspace_bytes(p));
   if (rc) return rc;
   p.part = g_ops.ws;
+  if (dtp_is_ws_tile(tile)) return dtp_launch_conv_ws(p, tile - DTP_TILE_WS0, (hipStream_t)s);
   if (p.flags & GF_ROWSTATS) {
     int bm = 0, bn = 64, ns = 0;
     (void)dtp_gemm_tile_dims(tile, &bm, &bn, &ns);
@@ -151,6 +154,11 @@ int dtp_op_pack_conv(const float* w, void* out, int Cout, int Cin, int Cin_pad, 
 int dtp_op_pack_conv_cb(const float* w, void* out, int Cout, int Cin, int ldw, dtp_stream s) {
   return dtp_launch_pack_conv_weight_cb(w, (f16*)out, Cout, Cin, ldw, (hipStream_t)s);
 }
+
+int dtp_op_pack_conv_ws(const float* w, const float* w1, void* out, int Cout, int Cin, int Cin2, dtp_stream s) {
+  return dtp_launch_pack_conv_ws(w, w1, (f16*)out, Cout, Cin, Cin2, (hipStream_t)s);
+}
+long long dtp_op_pack_conv_ws_elems(int Cout, int Cin, int Cin2) { return (long long)dtp_conv_ws_packed_elems(Cout, Cin, Cin2); }
 
 int dtp_op_groupnorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
                      int groups, float eps, int silu, dtp_stream s) {

@@ -25,6 +25,7 @@ struct Staged {
 struct ConvW {  // 3x3 (taps = 9) or 1x1 (taps = 1) convolution / any Linear (taps = 1)
   f16* w = nullptr;
   f16* wcb = nullptr;  // 3x3 only: channel-block-major packing for conv_halo_kernel (Cin % 64 == 0, no fused shortcut)
+  f16* wfr = nullptr;  // 3x3 of the UNet only: MFMA-fragment-order packing for convws_kernel (conv_ws.hip; Cin % 64 == 0, the 3x3 part)
   float* b = nullptr;  // fp32 bias (may be null)
   float* lns = nullptr;  // LayerNorm folded in: row sums of the packed weights (GF_LNFOLD)
   int cout = 0, cin = 0 /* padded */, cin_true = 0, taps = 1, K = 0, ldw = 0;
@@ -50,7 +51,7 @@ struct Ctx;
 // A launch program: a flat list of closures bound to statically planned buffers.
 using Op = std::function<int(hipStream_t, int /*step*/)>;
 // profiling classes (dtp_profile_rows): 0-11 = gemm_kernel<BM,BN,NS> variants (id = shape + 4*(NS-2)), then the rest
-enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_BIG0 = 21, PK_WIDE0 = 25, PK_FP8 = 27, PK_KH2 = 28, PK_LW = 36, PK_XATTN = 44, PK_HALO3 = 45, PK_LNLIN = 47, PK_COUNT = 48 };
+enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_BIG0 = 21, PK_WIDE0 = 25, PK_FP8 = 27, PK_KH2 = 28, PK_LW = 36, PK_XATTN = 44, PK_HALO3 = 45, PK_LNLIN = 47, PK_WS0 = 48, PK_COUNT = 50 };
 struct ProfRec {
   int kind;
   double flops, bytes;
@@ -246,6 +247,7 @@ struct Ctx {
   bool fuse_xattn = true;         // the two grouped GEMMs of a cross-attention as one launch (xattn.hip; $DTP_NO_XATTN=1: off, A/B)
   bool fold_gn_linear = true;     // transformer GroupNorm folded into per-sample proj_in weights at HW >= 1024 ($DTP_NO_FOLD_GN=1: off, A/B)
   bool fuse_reduce_gn = true;     // fold a split-K conv's reduce into the GroupNorm that consumes it ($DTP_NO_FUSE_REDUCE_GN=1: off, A/B)
+  bool pack_ws = false;           // load_conv also builds the fragment-order packing (set while the UNet's weights load; $DTP_NO_WS=1: never)
   bool fp8_linear = false;        // UNet transformer Linears / 1x1 convs on the fp8 MX MFMA (configs[4]); fixed once a UNet program exists
   bool fp8_attention = false;     // UNet self-attention on the fp8 MX MFMA (BASELINE configs[4]); fixed once a UNet program exists
   bool finite_pending = false;    // the last stamp ran the check; dtp_last_stamp_finite reads the flag

@@ -121,6 +121,12 @@ int load_conv(Ctx* c, const std::string& name, ConvW& w, int cin_pad, bool bias)
     w.wcb = (f16*)p2;
     RC(dtp_launch_pack_conv_weight_cb(s->d, w.wcb, cout, cin, w.ldw, 0));
   }
+  if (c->pack_ws && taps == 9 && (cin & 63) == 0 && cout >= 32) {  // third packing: fragment order for the weight-streaming kernel
+    void* p3;
+    RC(ctx_arena_alloc(c, dtp_conv_ws_packed_elems(cout, cin, 0) * 2, &p3));
+    w.wfr = (f16*)p3;
+    RC(dtp_launch_pack_conv_ws(s->d, nullptr, w.wfr, cout, cin, 0, 0));
+  }
   w.b = nullptr;
   if (bias) {
     const Staged* b = ctx_find(c, name + ".bias");
@@ -151,6 +157,12 @@ int load_conv_with_shortcut(Ctx* c, const std::string& conv, const std::string& 
   w.wcb = (f16*)p2;
   RC(dtp_launch_pack_conv_weight_cb(s->d, w.wcb, cout, cin, w.ldw, 0));
   RC(dtp_launch_pack_conv_weight(t->d, w.wcb + 9 * cin, cout, cin2, cin2, 1, w.ldw, 0));
+  if (c->pack_ws && (cin & 63) == 0 && cout >= 32) {  // fragment order for the weight-streaming kernel: 3x3 part, then the shortcut
+    void* p3;
+    RC(ctx_arena_alloc(c, dtp_conv_ws_packed_elems(cout, cin, cin2) * 2, &p3));
+    w.wfr = (f16*)p3;
+    RC(dtp_launch_pack_conv_ws(s->d, t->d, w.wfr, cout, cin, cin2, 0));
+  }
   std::vector<float> b1, b2;
   RC(ctx_fetch_host(c, conv + ".bias", b1));
   RC(ctx_fetch_host(c, shortcut + ".bias", b2));
@@ -480,12 +492,13 @@ void tune_cache_load(Ctx* c) {
 // not 128 wide, or a split LayerNorm-fold would otherwise reach the kernels.
 static bool tune_entry_valid(const GemmParams& p, int tile, int sp) {
   if (sp < 1 || (sp > p.nkb && tile != DTP_TILE_LNLIN)) return false;
-  if (tile != DTP_TILE_LNLIN) {
+  if (tile != DTP_TILE_LNLIN && !dtp_is_ws_tile(tile)) {
     int kbps, n;
     dtp_split_k(p.nkb, tile, sp, &kbps, &n);
     if (n != sp) return false;  // not a factor this tile can realise
   }
   if (tile == DTP_TILE_LNLIN) return dtp_lnlin_supported(p, sp);
+  if (dtp_is_ws_tile(tile)) return dtp_conv_ws_supported(p, tile - DTP_TILE_WS0, sp);
   const bool halo = dtp_is_halo_tile(tile);
   if (halo) return p.Wcb && (tile >= 48 ? dtp_conv_halo3_supported(p) : dtp_conv_halo_supported(p)) && p.batch <= 1;
   if (p.flags & GF_GNAPPLY) return false;  // only the halo kernel normalises its staged input
@@ -522,7 +535,10 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   int kl = snprintf(key, sizeof(key), "k8|%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", p.M, p.N, p.K, p.flags & ~GF_MFAST, p.Hi, p.Wi, p.Cin,
                     p.stride, p.lda, p.ldc, p.ldw, p.st_parts, p.Cin2, p.lda2);
   if (p.batch > 1) kl += snprintf(key + kl, sizeof(key) - kl, ",b%d", p.batch);
-  if (p.W8) snprintf(key + kl, sizeof(key) - kl, ",f8");
+  if (p.W8) kl += snprintf(key + kl, sizeof(key) - kl, ",f8");
+  // problems the weight-streaming conv can take were tuned without it by older tables: their key carries a marker
+  const int ws_variant = (p.Wfr && (p.flags & GF_CONV3)) ? (dtp_conv_ws_supported(p, 0, 1) ? 0 : dtp_conv_ws_supported(p, 1, 1) ? 1 : -1) : -1;
+  if (ws_variant >= 0) snprintf(key + kl, sizeof(key) - kl, ",ws");
   auto it = c->tuned.find(key);
   if (it != c->tuned.end() && !tune_entry_valid(p, it->second.first, it->second.second)) {
     fprintf(stderr, "[dtp] tune table entry '%s' -> (%d, %d) does not fit the problem; re-tuning\n", key, it->second.first, it->second.second);
@@ -562,6 +578,7 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
         if (q.R) RC(dtp_launch_touch(q.R, (size_t)q.M * q.ldr * 2, (float*)c->tune_thrash, 0));
         HIP_CHECK(hipEventRecord(c->tune_ev[0], 0));
         if (tile == DTP_TILE_LNLIN) RC(dtp_launch_lnlin(q, sp, 0));
+        else if (dtp_is_ws_tile(tile)) RC(dtp_launch_conv_ws(q, tile - DTP_TILE_WS0, 0));
         else if (halo) RC(dtp_launch_conv_halo(q, dtp_halo_variant(tile), 0)); else RC(dtp_launch_gemm(q, tile, 0));
         HIP_CHECK(hipEventRecord(c->tune_ev[1], 0));
         HIP_CHECK(hipEventSynchronize(c->tune_ev[1]));
@@ -642,6 +659,16 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
           if (ms >= 0.f) cands.push_back({ms, tile, sp});
         }
     }
+    if (ws_variant >= 0) {  // the weight-streaming conv of the small maps: K-slices = ranges of whole channel blocks
+      static const bool no_ws = [] { const char* e = getenv("DTP_NO_WS"); return e && e[0] && e[0] != '0'; }();
+      static const int slices[] = {1, 2, 3, 4, 5, 6, 8, 10};
+      for (int sp : slices) {
+        if (no_ws || !dtp_conv_ws_supported(p, ws_variant, sp)) continue;
+        float ms;
+        RC(time_cfg(DTP_TILE_WS0 + ws_variant, sp, 5, &ms));
+        if (ms >= 0.f) cands.push_back({ms, DTP_TILE_WS0 + ws_variant, sp});
+      }
+    }
     // second round: the three fastest candidates are usually within the measurement noise of each other -- time them again,
     // longer, and keep the minimum over both rounds
     std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.ms < y.ms; });
@@ -664,6 +691,7 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
       for (int rep = 0; rep < 4; ++rep) {
         HIP_CHECK(hipEventRecord(c->tune_ev[0], 0));
         if (bt == DTP_TILE_LNLIN) RC(dtp_launch_lnlin(q, bs, 0));
+        else if (dtp_is_ws_tile(bt)) RC(dtp_launch_conv_ws(q, bt - DTP_TILE_WS0, 0));
         else if (dtp_is_halo_tile(bt)) RC(dtp_launch_conv_halo(q, dtp_halo_variant(bt), 0)); else RC(dtp_launch_gemm(q, bt, 0));
         HIP_CHECK(hipEventRecord(c->tune_ev[1], 0));
         HIP_CHECK(hipEventSynchronize(c->tune_ev[1]));
@@ -695,6 +723,7 @@ static Op make_gemm_op(Ctx* c, GemmParams p, int tile, int bias_step_off) {
     q.part = c->ws;
     if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;
     if (tile == DTP_TILE_LNLIN) return dtp_launch_lnlin(q, q.col_ranges, s);
+    if (dtp_is_ws_tile(tile)) return dtp_launch_conv_ws(q, tile - DTP_TILE_WS0, s);
     if (dtp_is_halo_tile(tile)) { q.W = q.Wcb; return dtp_launch_conv_halo(q, dtp_halo_variant(tile), s); }
     return dtp_launch_gemm(q, tile, s);
   };
@@ -728,7 +757,7 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   snprintf(lab, sizeof(lab), "%s M=%d N=%d K=%d tile=%d splits=%d%s%s%s%s", (p.flags & GF_CONV3) ? "conv3" : "gemm", p.M, p.N, p.K, tile,
            tile == DTP_TILE_LNLIN ? p.col_ranges : p.splits, (p.flags & GF_UPS2) ? " ups" : "", (p.flags & GF_GEGLU) ? (f8tile ? " geglu fp8" : " geglu") : (f8tile ? " fp8" : ""), p.stride == 2 ? " s2" : "",
            p.batch > 1 ? (" x" + std::to_string(p.batch)).c_str() : "");
-  const int kind = tile == DTP_TILE_LNLIN ? PK_LNLIN : tile >= 48 ? PK_HALO3 + tile - 48 : tile >= 40 ? PK_LW + tile - 40 : tile >= 32 ? PK_KH2 + tile - 32 : tile >= 24 ? PK_FP8 : tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
+  const int kind = dtp_is_ws_tile(tile) ? PK_WS0 + tile - DTP_TILE_WS0 : tile == DTP_TILE_LNLIN ? PK_LNLIN : tile >= 48 ? PK_HALO3 + tile - 48 : tile >= 40 ? PK_LW + tile - 40 : tile >= 32 ? PK_KH2 + tile - 32 : tile >= 24 ? PK_FP8 : tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
   const double flops = 2.0 * nb * p.M * (double)p.N * k_alg;
   prog_push(c, prog, kind, flops, bytes, make_gemm_op(c, p, tile, bias_step_off), lab);
   if (p.splits > 1) {  // a GroupNorm pushed next may take over the reduce (Builder::gn)
@@ -752,6 +781,7 @@ int Builder::conv3(const T& x, const ConvW& w, int stride, int pad, bool ups, in
   p.flags = GF_CONV3 | (ups ? GF_UPS2 : 0) | extra_flags;
   if (tail) { p.A2 = tail->p; p.lda2 = tail->ld; p.Cin2 = w.cin2; }
   p.Wcb = w.wcb;
+  p.Wfr = w.wfr;
   if (extra_flags & GF_GNAPPLY) {
     if (!gn_fused.active) { dtp_set_error("conv3: GF_GNAPPLY without GroupNorm parameters"); return DTP_ERR_ARG; }
     p.gn_part = gn_fused.part; p.gn_gamma = gn_fused.gamma; p.gn_beta = gn_fused.beta; p.gn_eps = gn_fused.eps;

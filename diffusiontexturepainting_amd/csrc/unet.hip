@@ -3,6 +3,7 @@
 // Reference: trt_inference/models.py:1017-1139 (model + LoRA merge + engine I/O); topology
 // SURVEY.md Appendix A.1.
 #include <math.h>
+#include <stdlib.h>
 
 #include "engine.h"
 
@@ -80,6 +81,11 @@ static int merge_lora(Ctx* c) {
 
 int load_unet_weights(Ctx* c) {
   RC(merge_lora(c));
+  struct WsScope {  // the UNet's 3x3 convs also get the fragment-order packing (conv_ws.hip)
+    Ctx* c;
+    explicit WsScope(Ctx* cc) : c(cc) { const char* e = getenv("DTP_NO_WS"); c->pack_ws = !(e && e[0] && e[0] != '0'); }
+    ~WsScope() { c->pack_ws = false; }
+  } ws_scope(c);
   UNetW& u = c->unet;
   const std::string P = "unet.";
   int toff = 0, kvn = 0;

@@ -51,6 +51,19 @@ def pack_conv_cb(w):
     return out
 
 
+def pack_conv_ws(w, w1=None):
+    """w f32 [Cout,Cin,3,3] (Cin % 64 == 0) -> the MFMA-fragment-order packing convws_kernel streams (tile ids 51 / 52); w1 f32
+    [Cout,Cin2(,1,1)]: the 1x1 weights of a fused shortcut, packed behind the 3x3 fragments."""
+    lib = _lib.load()
+    cout, cin = w.shape[:2]
+    cin2 = w1.shape[1] if w1 is not None else 0
+    out = torch.zeros(lib.dtp_op_pack_conv_ws_elems(cout, cin, cin2), dtype=torch.float16, device=w.device)
+    w = w.contiguous().float()
+    w1 = w1.reshape(cout, cin2).contiguous().float() if w1 is not None else None
+    check(lib.dtp_op_pack_conv_ws(ptr(w), ptr(w1), ptr(out), cout, cin, cin2, _stream()), "pack_conv_ws")
+    return out
+
+
 def rowsum(wp, k):
     """fp32 row sums of packed fp16 weights over the first k columns (the `lns` vector of a LayerNorm-folded GEMM)."""
     lib = _lib.load()
@@ -117,7 +130,7 @@ def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, ou
 
 
 def conv3x3(x, wp, cout, stride=1, pad=1, upsample=False, bias=None, resid=None, tile=-1, splits=0, out_hw=None, flags=0,
-            tail=None, wcb=None):
+            tail=None, wcb=None, wfr=None):
     """x f16 NHWC [B,H,W,C] -> f16 NHWC [B,Ho,Wo,cout].  pad is the top/left zero padding; bottom/right
     padding is implied by out_hw (default: the symmetric-padding output size)."""
     lib = _lib.load()
@@ -139,6 +152,8 @@ def conv3x3(x, wp, cout, stride=1, pad=1, upsample=False, bias=None, resid=None,
     d.tile, d.splits = tile, splits
     if wcb is not None:
         d.Wcb = wcb.data_ptr()
+    if wfr is not None:
+        d.Wfr = wfr.data_ptr()
     check(lib.dtp_op_gemm(C.byref(d), _stream()), "conv3x3")
     return out
 

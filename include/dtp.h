@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DTP_ABI_VERSION 2
+#define DTP_ABI_VERSION 3
 
 /* error codes (every entry point returns one; dtp_last_error() has the text) */
 enum { DTP_OK = 0, DTP_ERR_ARG = 1, DTP_ERR_HIP = 2, DTP_ERR_STATE = 3, DTP_ERR_MISSING = 4 };
@@ -127,7 +127,8 @@ int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes);
  * 25-26 = gemm_wide_kernel<256,256> / <256,320> (8-wave wide tiles), 27 = gemm_fp8_kernel (all tiles),
  * 28-35 = gemm_kernel<BM,BN,NS,2> (the 8-wave twins of shapes 0..3 at 2 / 3 stages), 36-43 = gemm_kernel<BM,BN,3,1,LW> (4 / 8 loader
  * waves), 44 = xattn_kernel (fused cross-attention GEMM pair), 45-46 = conv_halo_kernel<8,8,64|128> with three images per workgroup,
- * 47 = lnlin_kernel (activation-stationary LayerNorm-folded Linear / GEGLU).  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
+ * 47 = lnlin_kernel (activation-stationary LayerNorm-folded Linear / GEGLU), 48-49 = convws_kernel (weight-streaming 3x3 conv of the
+ * small maps: three 8x8 images / one 16x16 image per workgroup).  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
  * dtp_profile(ctx, 0) switches back to graph replay.  The nvtx/cudaEvent hooks of
  * stable_diffusion_pipeline.py:146-149,486-503 are the reference counterpart. */
 typedef struct { int kind; int launches; double ms; double flops; double bytes; } dtp_prof_row;
@@ -172,7 +173,10 @@ typedef struct {
                         48 / 49 = conv_halo_kernel 8x8 x (64|128) with the same pixel tile of THREE consecutive images per
                         workgroup (image count % 3 == 0, needs Wcb);
                         50 = lnlin_kernel: DTP_GF_LNFOLD (+ BIAS, GEGLU) with K = 320 or 640, statistics computed in-kernel
-                        (st_in ignored); `splits` = column ranges per 128-row block (default 4) */
+                        (st_in ignored); `splits` = column ranges per 128-row block (default 4);
+                        51 / 52 = convws_kernel (weight-streaming 3x3 conv of the small maps, needs Wfr): 51 = 8x8 images in groups
+                        of three (image count % 3 == 0), 52 = 16x16 images; stride 1, pad 1, Cin % 64 == 0 (Cin2 % 64 == 0); `splits` =
+                        K-slices (ranges of whole 64-channel blocks) */
   int splits;        /* 0 = heuristic; >=1 = forced split-K factor (conv_halo_kernel: slices are whole 64-channel blocks) */
   const float* lns;  /* DTP_GF_LNFOLD: row sums of the packed weights (dtp_op_rowsum) */
   float ln_eps;
@@ -193,6 +197,7 @@ typedef struct {
                         [rows][ldw8] bytes, K padded to 128; with DTP_GF_LNFOLD the LayerNorm is applied while A is staged */
   int ldw8;
   float a_scale, w_scale; /* A8 = e4m3(A / a_scale), W8 = e4m3(W / w_scale) (powers of two); the product is applied to the accumulators */
+  const void* Wfr;   /* 3x3 conv, tile 51 / 52: the weights in MFMA fragment order (dtp_op_pack_conv_ws) */
 } dtp_gemm_desc;
 enum { DTP_GF_BIAS = 1, DTP_GF_BIAS_M = 2, DTP_GF_RESID = 4, DTP_GF_GEGLU = 8, DTP_GF_GELU = 64, DTP_GF_QUICKGELU = 128,
        DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512, DTP_GF_LNFOLD = 1024, DTP_GF_ROWSTATS = 2048, DTP_GF_SOFTMAX16 = 4096 };
@@ -209,6 +214,11 @@ int dtp_op_quantize_w8(const void* w, int ldw, int K, int rows, void* out, int l
 int dtp_op_pack_conv(const float* w, void* out, int Cout, int Cin, int Cin_pad, int taps, int ldw, dtp_stream s);
 /* w f32 [Cout][Cin][3][3] -> out f16 [rows][ldw], k' = ((ci/64)*9 + tap)*64 + ci%64 (Cin % 64 == 0; caller zero-fills out) */
 int dtp_op_pack_conv_cb(const float* w, void* out, int Cout, int Cin, int ldw, dtp_stream s);
+/* w f32 [Cout][Cin][3][3] (Cin % 64 == 0) -> out f16, dtp_op_pack_conv_ws_elems(Cout, Cin, Cin2) elements: 1 KB fragments in the order
+ * ((n-tile of 32 output channels, 64-channel block, channel quarter, tap), lane, 8 channels) that convws_kernel's waves stream; w1 (NULL
+ * or f32 [Cout][Cin2], Cin2 % 64 == 0) = the 1x1 weights of a fused shortcut (desc.A2), packed behind them */
+int dtp_op_pack_conv_ws(const float* w, const float* w1, void* out, int Cout, int Cin, int Cin2, dtp_stream s);
+long long dtp_op_pack_conv_ws_elems(int Cout, int Cin, int Cin2);
 int dtp_op_groupnorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
                      int groups, float eps, int silu, dtp_stream s);
 /* measured ceilings of this GPU (bench.py roofline.peak_measured): dense fp16 MFMA TFLOP/s with random operands on every SIMD, and

@@ -28,7 +28,7 @@ def test_header_and_binding_agree(lib):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), f"libdtp.so does not export {name}"
-    assert lib.dtp_abi_version() == 2
+    assert lib.dtp_abi_version() == 3
 
 
 def test_ddim_tables_match_reference_fixture(lib, golden_dir):

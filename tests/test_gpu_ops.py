@@ -350,6 +350,44 @@ def test_conv3x3_halo_kernel(ops, case):
     close(got, ref)
 
 
+WS_CASES = [
+    # B, H(=W), Cin, Cout, tile (51: 8x8 images in groups of three, 52: 16x16 images), K-slices
+    (3, 8, 1280, 1280, 51, 5), (3, 8, 128, 64, 51, 1), (3, 8, 192, 96, 51, 2), (6, 8, 640, 320, 51, 3), (3, 8, 2560, 1280, 51, 8),
+    (3, 16, 1280, 1280, 52, 2), (1, 16, 64, 32, 52, 1), (2, 16, 320, 100, 52, 5), (3, 16, 640, 1280, 52, 1),
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES)
+def test_conv3x3_weight_streaming_kernel(ops, case):
+    """convws_kernel (weights in MFMA fragment order straight into registers, contraction split over the four waves) vs torch conv2d:
+    split launches through the slab reduce, unsplit ones through the kernel's own bias / residual epilogue."""
+    b, h, cin, cout, tile, splits = case
+    x = rnd(b, h, h, cin, seed=53)
+    wt = rnd(cout, cin, 3, 3, seed=54, scale=(9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(55))
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float(), bias, padding=1).permute(0, 2, 3, 1)
+    res = rnd(*ref.shape, seed=56)
+    ref = ref + res.float()
+    wf = wt.float().cuda()
+    got = ops.conv3x3(x.cuda(), ops.pack_conv(wf), cout, bias=bias.cuda(), resid=res.cuda(), wfr=ops.pack_conv_ws(wf), tile=tile, splits=splits)
+    close(got, ref)
+
+
+@pytest.mark.parametrize("b,h,cin,cin2,cout,tile,splits", [(3, 8, 1280, 2560, 1280, 51, 5), (3, 8, 128, 64, 96, 51, 1), (6, 8, 320, 448, 320, 51, 2),
+                                                           (3, 16, 1280, 1920, 1280, 52, 2), (1, 16, 64, 320, 64, 52, 1), (2, 16, 640, 640, 100, 52, 3)])
+def test_conv3x3_weight_streaming_fused_shortcut(ops, b, h, cin, cin2, cout, tile, splits):
+    """convws_kernel with the ResBlock's 1x1 shortcut: its dense blocks go from memory straight into the B-operand registers, their
+    weight fragments follow the 3x3 fragments; every K-slice takes its share of both ranges (block counts that 3 does not divide)."""
+    t, x = rnd(b, h, h, cin, seed=64), rnd(b, h, h, cin2, seed=65)
+    w3 = rnd(cout, cin, 3, 3, seed=66, scale=(9 * cin) ** -0.5)
+    w1 = rnd(cout, cin2, 1, 1, seed=67, scale=cin2 ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(68))
+    ref = F.conv2d(t.float().permute(0, 3, 1, 2), w3.float(), bias, padding=1) + F.conv2d(x.float().permute(0, 3, 1, 2), w1.float())
+    wp = torch.cat([ops.pack_conv(w3.float().cuda())[:, : 9 * cin], ops.pack_conv(w1.float().cuda())[:, :cin2]], dim=1).contiguous()
+    got = ops.conv3x3(t.cuda(), wp, cout, bias=bias.cuda(), tail=x.cuda(), wfr=ops.pack_conv_ws(w3.float().cuda(), w1.float().cuda()), tile=tile, splits=splits)
+    close(got, ref.permute(0, 2, 3, 1))
+
+
 @pytest.mark.parametrize("b,h,cin,cin2,cout,variant,splits", [(2, 16, 64, 128, 64, 12, 1), (3, 8, 320, 640, 320, 14, 1), (1, 16, 128, 64, 256, 13, 3),
                                                               (3, 8, 1280, 2560, 1280, 15, 7), (2, 32, 320, 960, 320, 12, 2),
                                                               (3, 8, 320, 640, 320, 48, 1), (3, 8, 1280, 2560, 1280, 49, 7), (6, 16, 320, 640, 640, 49, 3)])
