@@ -33,7 +33,7 @@ PROF_KINDS = [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 
     [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 4}, 2>" for i in range(8)] + \
     [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, 3, 1, {(4, 8)[i // 4]}>" for i in range(8)] + \
     ["xattn_kernel (cross-attention GEMM pair)", "conv_halo_kernel<8, 8, 64, 3 images>", "conv_halo_kernel<8, 8, 128, 3 images>",
-     "lnlin_kernel (activation-stationary LayerNorm-folded Linear / GEGLU)", "convws_kernel<8, 8, 3 images>", "convws_kernel<16, 16>"]
+     "lnlin_kernel (activation-stationary LayerNorm-folded Linear / GEGLU)", "convws_kernel<8, 8, 3 images>", "convws_kernel<16, 16>", "convws_kernel<8, 16, 2 n-tiles>", "convws_kernel<8, 16, 2 n-tiles, 2 workgroups per CU>"]
 
 
 class GemmDesc(C.Structure):

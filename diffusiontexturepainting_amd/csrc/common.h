@@ -288,9 +288,10 @@ void dtp_gemm_wide_init();
 inline bool dtp_is_halo_tile(int tile) { return (tile >= 12 && tile < 16) || tile == 48 || tile == 49; }
 inline int dtp_halo_variant(int tile) { return tile >= 48 ? tile - 44 : tile - 12; }
 constexpr int DTP_TILE_LNLIN = 50;  // lnlin_kernel (lnlin.hip): the "splits" of a tune entry are its column ranges, K is not split
-constexpr int DTP_TILE_WS0 = 51;    // convws_kernel (conv_ws.hip): 51 = three 8 x 8 images, 52 = one 16 x 16 image per workgroup; splits = K-slices
-constexpr int DTP_TILE_IDS = 53;    // tile ids are 0 .. DTP_TILE_IDS - 1
-inline bool dtp_is_ws_tile(int tile) { return tile == DTP_TILE_WS0 || tile == DTP_TILE_WS0 + 1; }
+constexpr int DTP_TILE_WS0 = 51;    // convws_kernel (conv_ws.hip): 51 = three 8 x 8 images, 52 = one 16 x 16 image, 53 = an 8 x 16 pixel tile x 64 channels per workgroup, 54 = the same for two co-resident workgroups per CU; splits = K-slices
+constexpr int DTP_WS_VARIANTS = 4;
+constexpr int DTP_TILE_IDS = 55;    // tile ids are 0 .. DTP_TILE_IDS - 1
+inline bool dtp_is_ws_tile(int tile) { return tile >= DTP_TILE_WS0 && tile < DTP_TILE_WS0 + DTP_WS_VARIANTS; }
 // Split-K of a problem of nkb 64-wide k-blocks into (at most) sp slices.  conv_halo_kernel unrolls the nine taps of a channel block:
 // its slices are multiples of 9 k-blocks (the 9 * Cin/64 conv blocks come first, so no channel block is cut).
 inline void dtp_split_k(int nkb, int tile, int sp, int* kb_per_split, int* splits) {
@@ -306,7 +307,7 @@ inline void dtp_split_k(int nkb, int tile, int sp, int* kb_per_split, int* split
 bool dtp_lnlin_supported(const GemmParams& p, int nsplit);
 int dtp_launch_lnlin(const GemmParams& p, int nsplit, hipStream_t s);
 void dtp_lnlin_init();
-// conv_ws.hip: weight-streaming 3x3 conv of the small feature maps (variant 0: three 8 x 8 images, 1: one 16 x 16 image per workgroup)
+// conv_ws.hip: weight-streaming 3x3 conv (variant 0: three 8 x 8 images, 1: one 16 x 16 image, 2: an 8 x 16 tile x 64 channels per workgroup)
 bool dtp_conv_ws_supported(const GemmParams& p, int variant, int nsplit);
 int dtp_launch_conv_ws(const GemmParams& p, int variant, hipStream_t s);
 void dtp_conv_ws_init();

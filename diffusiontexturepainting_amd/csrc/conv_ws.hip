@@ -41,7 +41,10 @@ __device__ __forceinline__ f16x8 lds_read16_off(uint32_t addr) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TH, int TW, int NI>
+// CO: the configuration for TWO co-resident workgroups per CU (<= 80 KB of LDS, <= 256 registers): the four partial tiles are combined
+// one n-tile at a time (the combine area is then no larger than the three patch buffers) and the patch fragments use two register
+// sets instead of three (no request across the channel-block boundary: the co-resident workgroup's waves cover that latency).
+template <int TH, int TW, int NI, int NT, bool CO = false>
 struct WsGeom {
   static constexpr int PW = TW + 3, PH = TH + 2;        // patch pitch (odd) and rows, in pixel slots
   static constexpr int HP1 = PH * PW, HP = NI * HP1;    // slots per image / per pixel group
@@ -50,11 +53,15 @@ struct WsGeom {
   static constexpr int TM = NI * TH * TW / 32;          // 32-pixel MFMA tiles of the group
   static constexpr int RPT = 32 / TW, TPI = TH / RPT;   // image rows per tile, tiles per image
   static constexpr int CBLK = 1152;                     // pitch of a 1 KB (wave, tile, register group) block of the combine area
-  static constexpr int CMB = 4 * TM * 4 * CBLK;         // the four waves' partial tiles (fp32)
+  static constexpr int CMB = 4 * (CO ? 1 : NT) * TM * 4 * CBLK;  // the four waves' partial tiles (fp32) of one combine round
   static constexpr int LDS = (3 * PBYTES > CMB ? 3 * PBYTES : CMB);
+  static constexpr int LT = (HL - 1) / (NT * TM);       // the tap in which the last patch piece of a channel block is issued
+  static constexpr int WAITB = (17 - LT) * NT;          // vmcnt at the per-block barrier (see the main loop)
   static_assert(TW == 8 || TW == 16, "pixel tile width");
   static_assert(TH % RPT == 0 && (NI * TH * TW) % 32 == 0, "whole MFMA tiles");
   static_assert(HP * 128 < 65536, "fragment offsets are 16-bit immediates");
+  static_assert(LT < 8 && WAITB < 64, "patch pieces fit in the taps before the barrier; vmcnt is a 6-bit counter");
+  static_assert(LDS <= (CO ? 80 : 160) * 1024, "LDS");
 };
 
 // Weight packing.  Fragment index f = ((nt * ncb + cb) * 4 + w) * 9 + tap; element e of lane l of fragment f is
@@ -95,48 +102,66 @@ __device__ __forceinline__ void rd_frags(f16x8 (&dst)[G::TM], uint32_t ct) {
   }
 }
 
-template <int TH, int TW, int NI, bool NTW>
-__global__ __launch_bounds__(256) void convws_kernel(const GemmParams p) {
-  using G = WsGeom<TH, TW, NI>;
-  constexpr int TM = G::TM, HL = G::HL, PW = G::PW, PH = G::PH, HP1 = G::HP1, PB = G::PBYTES;
+template <int TH, int TW, int NI, int NT, bool NTW, bool CO = false>
+__global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParams p) {
+  using G = WsGeom<TH, TW, NI, NT, CO>;
+  constexpr int TM = G::TM, HL = G::HL, PW = G::PW, PH = G::PH, HP1 = G::HP1, PB = G::PBYTES, NTM = NT * TM;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 31, fhalf = lane >> 5;
 
-  // ---- which (pixel group, n-tile, K-slice).  Block b runs on XCD b % 8: the pixel groups of one (n-tile, slice) unit read the same
-  // weight fragments, so they sit on ONE XCD next to each other (its L2 serves all but the first of them).
-  const int npg = p.M / (NI * TH * TW);
-  const int nts = (p.N + 31) >> 5, S = p.splits;
-  const int units = nts * S;
+  // ---- which (pixel group, n-range, K-slice).  A pixel group = the TH x TW tile (ty, tx) of NI consecutive images; an n-range = NT
+  // n-tiles of 32 output channels; a unit = (n-range, K-slice).  Block b runs on XCD b % 8.  With a multiple of 8 units (the deep
+  // levels: 40 n-tiles, megabytes of weights per unit) the pixel groups of one unit sit next to each other on ONE XCD, whose L2
+  // then serves all but the first reader of every weight fragment; otherwise (few units, many pixel groups: the wide levels, whose
+  // whole weight set fits any L2) the units of one pixel group sit on one XCD and share its patches.
+  const int H = p.Hi, W = p.Wi;
+  const int tiles_x = W / TW, tiles_y = H / TH;
+  const int npg = (p.M / (H * W) / NI) * tiles_y * tiles_x;
+  const int nts = (p.N + 31) >> 5, nrs = (nts + NT - 1) / NT, S = p.splits;
+  const int units = nrs * S;
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int pg = idx % npg, u = (idx / npg) * 8 + xcd;
-  if (u >= units) return;
-  const int z = u % S, nt = u / S;
+  int pg, u;
+  if ((units & 7) == 0) { pg = idx % npg; u = (idx / npg) * 8 + xcd; }
+  else { const int pgq = (npg + 7) >> 3; pg = (idx % pgq) * 8 + xcd; u = idx / pgq; }
+  if (u >= units || pg >= npg) return;
+  const int z = u % S, nr = u / S;
   const int ncb = p.Cin >> 6;
   const int mb0 = (int)((long long)z * ncb / S), mb1 = (int)((long long)(z + 1) * ncb / S);  // channel blocks [mb0, mb1)
-  const int img0 = pg * NI;
+  const int tx = pg % tiles_x, ty = (pg / tiles_x) % tiles_y;
+  const int img0 = (pg / (tiles_x * tiles_y)) * NI;
+  const int y0 = ty * TH, x0 = tx * TW;
 
-  // ---- weight ring first: fragment (cb, tap) of this wave's channel quarter; the nine loads of the first channel block are in flight
-  // while the patch addresses are computed
+  // ---- weight ring first: fragment (n-tile, cb, tap) of this wave's channel quarter; the loads of the first channel block are in
+  // flight while the patch addresses are computed.  An n-tile beyond N (odd n-tile count, NT = 2) loads zeros.
   const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wfr, 0, (int)0x80000000u, 0x00020000);
-  const int wvoff = lane * 16;
-  const int wbase = nt * ncb * 4 + wave;  // fragment index = ((wbase + cb * 4) * 9 + tap)
-  auto wload = [&](int cb, int tap) -> f16x8 {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff, ((wbase + cb * 4) * 9 + tap) * 1024, NTW ? 2 : 0);
+  constexpr int OOB = (int)0x80000000u;
+  int wvoff[NT], wbase[NT];  // fragment index = ((wbase + cb * 4) * 9 + tap)
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int nt = nr * NT + i;
+    wvoff[i] = nt < nts ? lane * 16 : OOB;
+    wbase[i] = (nt < nts ? nt : 0) * ncb * 4 + wave;
+  }
+  auto wload = [&](int i, int cb, int tap) -> f16x8 {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, wvoff[i], ((wbase[i] + cb * 4) * 9 + tap) * 1024, NTW ? 2 : 0);
     return __builtin_bit_cast(f16x8, v);
   };
-  f16x8 wf[9];
+  f16x8 wf[NT][9];
   if (mb0 < mb1) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wf[t] = wload(mb0, t);
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) wf[i][t] = wload(i, mb0, t);
   }
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- patch DMA: piece i of this wave covers pixel slots (i*4 + wave)*8 .. +7, lane -> (slot, 16-byte position kc8); the position
-  // holds source chunk kc8 ^ (hx & 7).  Halo / pad slots carry offset -1: out of range of the descriptor, the DMA writes zeros.
-  // Slot s = il * HP1 + hy * PW + hx; consecutive pieces are 32 slots apart: (il, hy, hx) advance incrementally (no divisions).
+  // holds source chunk kc8 ^ (hx & 7).  Slots outside the image (or the pad column / the buffer's tail) carry offset -1: out of
+  // range of the descriptor, the DMA writes zeros.  Slot s = il * HP1 + hy * PW + hx; consecutive pieces are 32 slots apart:
+  // (il, hy, hx) advance incrementally (no divisions).
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)0x80000000u, 0x00020000);
   int voffA[HL];
   {
@@ -145,8 +170,9 @@ __global__ __launch_bounds__(256) void convws_kernel(const GemmParams p) {
     constexpr int DY = 32 / PW, DX = 32 - DY * PW;
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
-      const bool ok = il < NI && (unsigned)(hy - 1) < (unsigned)TH && (unsigned)(hx - 1) < (unsigned)TW;
-      voffA[i] = ok ? ((((img0 + il) * TH + hy - 1) * TW + hx - 1) * p.lda + (((lane & 7) ^ (hx & 7)) << 3)) * 2 : -1;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      const bool ok = il < NI && hx < TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      voffA[i] = ok ? ((((img0 + il) * H + iy) * W + ix) * p.lda + (((lane & 7) ^ (hx & 7)) << 3)) * 2 : -1;
       hx += DX; hy += DY;
       if (hx >= PW) { hx -= PW; ++hy; }
       if (hy >= PH) { hy -= PH; ++il; }
@@ -156,13 +182,12 @@ __global__ __launch_bounds__(256) void convws_kernel(const GemmParams p) {
     const int vo = voffA[i];
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(smem + bo + (i * 4 + wave) * 1024), 16, vo, cb * 128, 0, 0);
   };
-  auto a_piece = [&](int buf, int cb, int i) { a_piece_at((uint32_t)(buf * PB), cb, i); };
   if (mb0 < mb1) {
 #pragma unroll
-    for (int i = 0; i < HL; ++i) a_piece(0, mb0, i);
+    for (int i = 0; i < HL; ++i) a_piece_at(0u, mb0, i);
     if (mb0 + 1 < mb1) {
 #pragma unroll
-      for (int i = 0; i < HL; ++i) a_piece(1, mb0 + 1, i);
+      for (int i = 0; i < HL; ++i) a_piece_at((uint32_t)PB, mb0 + 1, i);
     }
   }
 
@@ -174,20 +199,26 @@ __global__ __launch_bounds__(256) void convws_kernel(const GemmParams p) {
   for (int kx = 0; kx < 3; ++kx)
     colterm[kx] = lds_addr(smem) + (pyl * PW + pxl + kx) * 128 + ((((2 * wave + fhalf) ^ ((pxl + kx) & 7))) << 4);
 
-  f32x16 acc[TM];
+  f32x16 acc[NT][TM];
 #pragma unroll
-  for (int j = 0; j < TM; ++j)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- main loop.  patch(cb) lives in buffer (cb - mb0) % 3; its pieces are issued during taps 0-1 of cb - 2 (one after each MFMA).
-  // One barrier per channel block, at the start of tap 8 and after this wave's last reads of patch(cb) have returned: it publishes
-  // patch(cb + 1) to every wave, and it is what makes the buffer of patch(cb) free for the pieces of patch(cb + 3), which are
-  // issued after it (taps 0-1 of cb + 1).  The fragments of the next tap are always requested one tap ahead, across the channel-block
-  // boundary too (three fragment sets: 9 taps = 0 mod 3), so no LDS latency is exposed anywhere.
-  // vmcnt at the barrier: the ops younger than the last piece of patch(cb + 1) are wload(cb, 1..8) and, during cb, the pieces of
-  // patch(cb + 2) (if any) and wload(cb + 1, 0..7): 16 or 16 + HL -- waiting for 16 is exact or stricter.
-  f16x8 bf[3][TM];
+  // ---- main loop.  patch(cb) lives in buffer (cb - mb0) % 3; its pieces are issued during the first taps of cb - 2 (one after each
+  // MFMA).  One barrier per channel block, at the start of tap 8 and after this wave's last reads of patch(cb) have returned: it
+  // publishes patch(cb + 1) to every wave, and it is what makes the buffer of patch(cb) free for the pieces of patch(cb + 3),
+  // which are issued after it (first taps of cb + 1).  The fragments of the next tap are always requested one tap ahead, across the
+  // channel-block boundary too (three fragment sets: 9 taps = 0 mod 3), so no LDS latency is exposed anywhere.  Every fragment feeds NT
+  // MFMAs: with one n-tile per wave the kernel is bound by the LDS read path (1 KB per MFMA; measured: removing the MFMAs changes
+  // nothing), with two it is not.
+  // vmcnt at the barrier: the ops younger than the last piece of patch(cb + 1) (issued in tap LT of cb - 1) are wload(cb, LT..8) and,
+  // during cb, the pieces of patch(cb + 2) (if any) and wload(cb + 1, 0..7): (17 - LT) NT, + HL -- waiting for the smaller count is
+  // exact or stricter.
+  constexpr int NBF = CO ? 2 : 3;
+  f16x8 bf[NBF][TM];
   auto rd = [&](auto tapc, uint32_t bo, f16x8 (&dst)[TM]) {
     constexpr int TAP = decltype(tapc)::value, KY = TAP / 3, KX = TAP % 3;
 #ifndef DTP_WS_NO_LDSREAD
@@ -205,7 +236,7 @@ __global__ __launch_bounds__(256) void convws_kernel(const GemmParams p) {
     auto do_cb = [&](auto morec, auto more2c, int cb, uint32_t bo, uint32_t bo1, uint32_t bo2) {
       constexpr bool MORE = decltype(morec)::value, MORE2 = decltype(more2c)::value;
       auto tap = [&](auto tapc) {
-        constexpr int TAP = decltype(tapc)::value, CUR = TAP % 3, NXT = (TAP + 1) % 3;
+        constexpr int TAP = decltype(tapc)::value, CUR = TAP % NBF, NXT = (TAP + 1) % NBF;
         __builtin_amdgcn_sched_barrier(0);
 #ifdef DTP_WS_NO_LDSREAD
 #define DTP_WS_WAIT(n, f) asm volatile("" ::: "memory")
@@ -219,35 +250,41 @@ __global__ __launch_bounds__(256) void convws_kernel(const GemmParams p) {
         } else {
           DTP_WS_WAIT(0, bf[CUR]);  // this wave's last reads of patch(cb) are complete
           if constexpr (MORE) {
-            wait_vmcnt<16>();
+            wait_vmcnt<G::WAITB>();
             __builtin_amdgcn_s_barrier();
-            rd(std::integral_constant<int, 0>{}, bo1, bf[NXT]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-#ifndef DTP_WS_NO_MFMA  // (diagnostic builds only: tools/ws_variants.sh)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[TAP], bf[CUR][j], acc[j], 0, 0, 0);
-#else
-          asm volatile("" : "+v"(acc[j]) : "v"(wf[TAP]), "v"(bf[CUR][j]));
-#endif
-          if constexpr (MORE2) {
-            if (TAP * TM + j < HL) {
-              __builtin_amdgcn_sched_barrier(0);
-#ifndef DTP_WS_NO_DMA
-              a_piece_at(bo2, cb + 2, TAP * TM + j);
-#endif
+            if constexpr (!CO) {
+              rd(std::integral_constant<int, 0>{}, bo1, bf[NXT]);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
         }
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int i = 0; i < NT; ++i) {
+#ifndef DTP_WS_NO_MFMA  // (diagnostic builds only: tools/ws_variants.sh)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][TAP], bf[CUR][j], acc[i][j], 0, 0, 0);
+#else
+            asm volatile("" : "+v"(acc[i][j]) : "v"(wf[i][TAP]), "v"(bf[CUR][j]));
+#endif
+            if constexpr (MORE2) {
+              if (TAP * NTM + j * NT + i < HL) {
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef DTP_WS_NO_DMA
+                a_piece_at(bo2, cb + 2, TAP * NTM + j * NT + i);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
         if constexpr (MORE) {
           __builtin_amdgcn_sched_barrier(0);
 #ifndef DTP_WS_NO_WLOAD
-          wf[TAP] = wload(cb + 1, TAP);
+#pragma unroll
+          for (int i = 0; i < NT; ++i) wf[i][TAP] = wload(i, cb + 1, TAP);
 #endif
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (CO && TAP == 8) rd(std::integral_constant<int, 0>{}, bo1, bf[0]);  // two sets: tap 8 has just released set 0
         }
       };
 #undef DTP_WS_WAIT
@@ -276,7 +313,7 @@ __global__ __launch_bounds__(256) void convws_kernel(const GemmParams p) {
   // half) reads 16 bytes of its pixel's row, and the four k-step loads of one pixel tile hit the same 32 lines back to back, so every
   // line crosses L2 -> L1 once per workgroup (the first version split each block's k-steps over the waves like the 3x3 part: four
   // waves x 32-byte pieces of every line = 4 x the L2 traffic, 13 us for the eight blocks of an M = 192 slice).  Tiles are requested
-  // D tiles ahead (a ring in the registers the patch fragments used), across block boundaries; blocks beyond the slice carry
+  // D tiles ahead (a register ring), across block boundaries; blocks beyond the slice carry
   // out-of-range offsets: zeros, which add nothing.  Weight fragments of block tb: tbase + tb * 4 + k-step, behind the 3x3 fragments.
   if (p.A2 && !(p.sm_valid & 1)) {
     const int ntb = p.Cin2 >> 6;
@@ -287,14 +324,16 @@ __global__ __launch_bounds__(256) void convws_kernel(const GemmParams p) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int il = j / G::TPI, py = G::RPT * (j % G::TPI) + pyl;
-        voffT[j] = ((((img0 + il) * TH + py) * TW + pxl) * p.lda2 + 8 * fhalf) * 2;
+        voffT[j] = ((((img0 + il) * H + y0 + py) * W + x0 + pxl) * p.lda2 + 8 * fhalf) * 2;
       }
-      const int tbase = nts * ncb * 36 + nt * ntb * 4;
-      constexpr int OOB = (int)0x80000000u;
-      constexpr int D = (TM % 4 == 0) ? 4 : 3;   // prefetch distance in pixel tiles; divides TM: ring slot = j % D
-      static_assert(TM % D == 0 && D <= 3 * TM / 4, "tile ring");
-      f16x8 (&ring)[3 * TM] = reinterpret_cast<f16x8 (&)[3 * TM]>(bf);  // 4 k-step fragments per ring slot: [slot * 4 + ks]
-      f16x8 wt[2][4];
+      int tbase[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) tbase[i] = nts * ncb * 36 + (nr * NT + i < nts ? nr * NT + i : 0) * ntb * 4;
+      constexpr int D = CO ? 2 : (TM % 4 == 0) ? 4 : 3;   // prefetch distance in pixel tiles; divides TM: ring slot = j % D
+      static_assert(TM % D == 0, "tile ring");
+      f16x8 ring[4 * D];  // 4 k-step fragments per ring slot: [slot * 4 + ks] (the patch fragments' registers are dead by now)
+      constexpr int WTB = CO ? 1 : 2;  // weight fragment sets: the co-resident build reloads one set per block (register budget)
+      f16x8 wt[WTB][NT][4];
       auto frag_load = [&](int tb, int j, int slot) {   // the four k-step fragments of pixel tile j of block tb
         const int vo = tb < tk1 ? voffT[j] : OOB;
 #pragma unroll
@@ -304,11 +343,14 @@ __global__ __launch_bounds__(256) void convws_kernel(const GemmParams p) {
         }
       };
       auto wt_load = [&](int tb, int par) {
-        const int vo = tb < tk1 ? wvoff : OOB;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, vo, (tbase + tb * 4 + ks) * 1024, NTW ? 2 : 0);
-          wt[par][ks] = __builtin_bit_cast(f16x8, v);
+        for (int i = 0; i < NT; ++i) {
+          const int vo = tb < tk1 ? wvoff[i] : OOB;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, vo, (tbase[i] + tb * 4 + ks) * 1024, NTW ? 2 : 0);
+            wt[par % WTB][i][ks] = __builtin_bit_cast(f16x8, v);
+          }
         }
       };
       const int nround = (tk1 - tk0 + 3) >> 2;  // blocks per wave (uniform: the surplus blocks are zeros)
@@ -317,15 +359,19 @@ __global__ __launch_bounds__(256) void convws_kernel(const GemmParams p) {
 #pragma unroll
       for (int j = 0; j < D; ++j) frag_load(tb, j, j);
       auto block = [&](auto parc, int tbc, bool more) {
-        constexpr int PAR = decltype(parc)::value;
-        if (more) wt_load(tbc + 4, PAR ^ 1);
+        constexpr int PAR = decltype(parc)::value % WTB;
+        if (WTB == 2 && more) wt_load(tbc + 4, PAR ^ 1);
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt[PAR][ks], ring[(j % D) * 4 + ks], acc[j], 0, 0, 0);
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt[PAR][i][ks], ring[(j % D) * 4 + ks], acc[i][j], 0, 0, 0);
           if (j + D < TM) frag_load(tbc, j + D, j % D);
           else if (more) frag_load(tbc + 4, j + D - TM, j % D);
         }
+        if (WTB == 1 && more) wt_load(tbc + 4, 0);
       };
       for (int r = 0; r < nround; r += 2) {
         block(std::integral_constant<int, 0>{}, tb, r + 1 < nround);
@@ -336,84 +382,98 @@ __global__ __launch_bounds__(256) void convws_kernel(const GemmParams p) {
   }
 
   // ---- the four partial tiles -> LDS, block (wave, tile, register group q) = 64 x 16 bytes at a 1152-byte pitch, slot 2 * pixel + half:
-  // thread t of pass j then sums the four waves' values of (pixel t / 8 of tile j, channels 4 (t % 8) ..) -- conflict-free for the
-  // lane groups of ds_read_b128 (tests/test_conv_ws_layout.py) -- and eight neighbouring lanes store one pixel's 128 contiguous bytes.
+  // thread t of pass (i, j) then sums the four waves' values of (pixel t / 8 of tile j, channels 4 (t % 8) .. of n-tile i) -- conflict-
+  // free for the lane groups of ds_read_b128 (tests/test_conv_ws_layout.py) -- and eight neighbouring lanes store one pixel's 128
+  // contiguous bytes.
   if (p.sm_valid & 2) return;
   __builtin_amdgcn_s_barrier();  // every wave has left the patches
   constexpr int CB = G::CBLK;
-  {
-    char* const mine = smem + wave * TM * 4 * CB + (frow * 2 + fhalf) * 16;
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 v = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
-        *(f32x4*)(mine + (j * 4 + q) * CB) = v;
-      }
-  }
-  __syncthreads();
+  constexpr int RT = CO ? 1 : NT;        // n-tiles per combine round
   const int epx = tid >> 3, c4 = tid & 7;            // pixel inside the tile, channel quad
-  const int n = nt * 32 + 4 * c4;
-  const bool ncol = n + 4 <= p.N;                    // N % 4 == 0 is required by the launcher
   const int epxl = epx % TW, epyl = epx / TW;
-  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-  if (p.splits == 1 && (p.flags & GF_BIAS) && ncol) bv = *(const f32x4*)(p.bias + n);
   const char* const src0 = smem + (c4 >> 1) * CB + (epx * 2 + (c4 & 1)) * 16;
 #pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const char* src = src0 + j * 4 * CB;
-    const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + TM * 4 * CB), v2 = *(const f32x4*)(src + 2 * TM * 4 * CB),
-                v3 = *(const f32x4*)(src + 3 * TM * 4 * CB);
-    f32x4 v;
+  for (int i0 = 0; i0 < NT; i0 += RT) {
+    if (i0 > 0) __syncthreads();  // the previous round's reads are done
+    {
+      char* const mine = smem + wave * RT * TM * 4 * CB + (frow * 2 + fhalf) * 16;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = ((v0[e] + v1[e]) + v2[e]) + v3[e];
-    const int il = j / G::TPI, py = G::RPT * (j % G::TPI) + epyl;
-    const size_t m = ((size_t)(img0 + il) * TH + py) * TW + epxl;
-    if (!ncol) continue;
-    if (p.splits > 1) {
-      *(f32x4*)(p.part + ((size_t)z * p.M + m) * p.N + n) = v;
-    } else {
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += bv[e];
-      if (p.flags & GF_RESID) {
-        const f16x4 r = *(const f16x4*)(p.R + m * p.ldr + n);
+        for (int j = 0; j < TM; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[i0 + i][j][4 * q], acc[i0 + i][j][4 * q + 1], acc[i0 + i][j][4 * q + 2], acc[i0 + i][j][4 * q + 3]};
+            *(f32x4*)(mine + ((i * TM + j) * 4 + q) * CB) = v;
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int n = (nr * NT + i0 + i) * 32 + 4 * c4;
+      const bool ncol = n + 4 <= p.N;                  // N % 4 == 0 is required by the launcher
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.splits == 1 && (p.flags & GF_BIAS) && ncol) bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const char* src = src0 + (i * TM + j) * 4 * CB;
+        const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + RT * TM * 4 * CB), v2 = *(const f32x4*)(src + 2 * RT * TM * 4 * CB),
+                    v3 = *(const f32x4*)(src + 3 * RT * TM * 4 * CB);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((v0[e] + v1[e]) + v2[e]) + v3[e];
+        const int il = j / G::TPI, py = G::RPT * (j % G::TPI) + epyl;
+        const size_t m = ((size_t)(img0 + il) * H + y0 + py) * W + x0 + epxl;
+        if (!ncol) continue;
+        if (p.splits > 1) {
+          *(f32x4*)(p.part + ((size_t)z * p.M + m) * p.N + n) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bv[e];
+          if (p.flags & GF_RESID) {
+            const f16x4 r = *(const f16x4*)(p.R + m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+          }
+          const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+          *(f16x4*)((f16*)p.C + m * p.ldc + n) = o;
+        }
       }
-      const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-      *(f16x4*)((f16*)p.C + m * p.ldc + n) = o;
     }
   }
 }
 
-template <int TH, int TW, int NI>
+template <int TH, int TW, int NI, int NT, bool CO = false>
 int launch_ws(const GemmParams& p, hipStream_t s) {
-  using G = WsGeom<TH, TW, NI>;
-  const int npg = p.M / (NI * TH * TW);
-  const int units = ((p.N + 31) >> 5) * p.splits;
-  const int blocks = ((units + 7) / 8) * 8 * npg;
+  using G = WsGeom<TH, TW, NI, NT, CO>;
+  const int npg = (p.M / (p.Hi * p.Wi) / NI) * (p.Hi / TH) * (p.Wi / TW);
+  const int nrs = (((p.N + 31) >> 5) + NT - 1) / NT;
+  const int units = nrs * p.splits;
+  const int blocks = (units & 7) == 0 ? units * npg : ((npg + 7) >> 3) * 8 * units;  // the kernel's two block -> (pixel group, unit) maps
   // a fragment that one workgroup reads once is streamed past the caches (nt); with several pixel groups per unit the L2 serves the
   // re-reads, so it keeps the default policy
   static const int dbg = [] { const char* e = getenv("DTP_WS_DEBUG"); return e ? atoi(e) : 0; }();
   GemmParams q = p;
   q.sm_valid = dbg & 3;
   const bool nt = (dbg & 4) ? false : (dbg & 8) ? true : npg == 1;
-  if (nt) hipLaunchKernelGGL((convws_kernel<TH, TW, NI, true>), dim3(blocks), dim3(256), G::LDS, s, q);
-  else hipLaunchKernelGGL((convws_kernel<TH, TW, NI, false>), dim3(blocks), dim3(256), G::LDS, s, q);
+  if (nt) hipLaunchKernelGGL((convws_kernel<TH, TW, NI, NT, true, CO>), dim3(blocks), dim3(256), G::LDS, s, q);
+  else hipLaunchKernelGGL((convws_kernel<TH, TW, NI, NT, false, CO>), dim3(blocks), dim3(256), G::LDS, s, q);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
-template <int TH, int TW, int NI>
+template <int TH, int TW, int NI, int NT, bool CO = false>
 void set_ws_attr() {
-  (void)hipFuncSetAttribute((const void*)convws_kernel<TH, TW, NI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WsGeom<TH, TW, NI>::LDS);
-  (void)hipFuncSetAttribute((const void*)convws_kernel<TH, TW, NI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WsGeom<TH, TW, NI>::LDS);
+  (void)hipFuncSetAttribute((const void*)convws_kernel<TH, TW, NI, NT, true, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, WsGeom<TH, TW, NI, NT, CO>::LDS);
+  (void)hipFuncSetAttribute((const void*)convws_kernel<TH, TW, NI, NT, false, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, WsGeom<TH, TW, NI, NT, CO>::LDS);
 }
 
 }  // namespace
 
 void dtp_conv_ws_init() {
-  set_ws_attr<8, 8, 3>();
-  set_ws_attr<16, 16, 1>();
+  set_ws_attr<8, 8, 3, 1>();
+  set_ws_attr<16, 16, 1, 1>();
+  set_ws_attr<8, 16, 1, 2>();
+  set_ws_attr<8, 16, 1, 2, true>();
 }
 
 // elements of the packing: the 3x3 fragments, then (Cin2 > 0) the fragments of the fused 1x1 shortcut
@@ -433,16 +493,22 @@ int dtp_launch_pack_conv_ws(const float* w, const float* w1, f16* out, int Cout,
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
-// variant 0: pixel group = three 8 x 8 images; variant 1: one 16 x 16 image.  Stride 1, pad 1, Cin % 64 == 0 (and Cin2 % 64 == 0 with
-// a fused shortcut), the image IS the tile.  nsplit K-slices (<= Cin / 64), each a range of whole channel blocks; nsplit > 1 leaves fp32 slabs.
+// variant 0: pixel group = three 8 x 8 images (the image IS the tile), one n-tile per workgroup; variant 1: one 16 x 16 image, one
+// n-tile; variant 2: an 8 x 16 pixel tile of one image of any size (H % 8 == 0, W % 16 == 0), TWO n-tiles (64 output channels) per
+// workgroup; variant 3: variant 2 built for two co-resident workgroups per CU (WsGeom CO).  Stride 1, pad 1, Cin % 64 == 0 (and Cin2 % 64 == 0 with a fused shortcut).  nsplit K-slices (<= Cin / 64), each a
+// range of whole channel blocks; nsplit > 1 leaves fp32 slabs.
 bool dtp_conv_ws_supported(const GemmParams& p, int variant, int nsplit) {
   if (!p.Wfr || !(p.flags & GF_CONV3) || p.batch > 1) return false;
   if (p.A2 && ((p.Cin2 & 63) || (p.lda2 & 7) || (size_t)p.M * p.lda2 * 2 >= ((size_t)1 << 31))) return false;
   if (p.flags & (GF_UPS2 | GF_GEGLU | GF_OUT_F32 | GF_LNFOLD | GF_ROWSTATS | GF_BIAS_M | GF_GELU | GF_QUICKGELU | GF_SILU | GF_GNAPPLY | GF_SOFTMAX16)) return false;
   if (p.stride != 1 || p.pad != 1 || (p.Cin & 63) || p.Ho != p.Hi || p.Wo != p.Wi || (p.N & 3) || (p.lda & 7) || (p.ldc & 3)) return false;
   if ((p.flags & GF_RESID) && (p.ldr & 3)) return false;
-  const int hw = variant == 0 ? 8 : 16, ni = variant == 0 ? 3 : 1;
-  if (variant < 0 || variant > 1 || p.Hi != hw || p.Wi != hw || p.M % (ni * hw * hw)) return false;
+  if (p.Hi < 1 || p.Wi < 1 || p.M % (p.Hi * p.Wi)) return false;
+  const int images = p.M / (p.Hi * p.Wi);
+  if (variant == 0) { if (p.Hi != 8 || p.Wi != 8 || images % 3) return false; }
+  else if (variant == 1) { if (p.Hi != 16 || p.Wi != 16) return false; }
+  else if (variant == 2 || variant == 3) { if ((p.Hi & 7) || (p.Wi & 15)) return false; }
+  else return false;
   if (nsplit < 1 || nsplit > p.Cin / 64) return false;
   if ((size_t)p.M * p.lda * 2 >= ((size_t)1 << 31) || dtp_conv_ws_packed_elems(p.N, p.Cin, p.A2 ? p.Cin2 : 0) * 2 >= ((size_t)1 << 31)) return false;
   return true;
@@ -453,7 +519,7 @@ int dtp_launch_conv_ws(const GemmParams& pin, int variant, hipStream_t s) {
     dtp_set_error("conv_ws: unsupported problem (M %d N %d Cin %d %dx%d flags %#x, variant %d, %d slices)", pin.M, pin.N, pin.Cin, pin.Hi, pin.Wi, pin.flags, variant, pin.splits);
     return DTP_ERR_ARG;
   }
-  const int rc = variant == 0 ? launch_ws<8, 8, 3>(pin, s) : launch_ws<16, 16, 1>(pin, s);
+  const int rc = variant == 0 ? launch_ws<8, 8, 3, 1>(pin, s) : variant == 1 ? launch_ws<16, 16, 1, 1>(pin, s) : variant == 2 ? launch_ws<8, 16, 1, 2>(pin, s) : launch_ws<8, 16, 1, 2, true>(pin, s);
   if (rc != DTP_OK) { dtp_set_error("conv_ws launch failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
   if (pin.splits > 1 && !(pin.flags & GF_NOREDUCE)) return dtp_launch_splitk_reduce(pin, s);
   return DTP_OK;

@@ -537,8 +537,10 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   if (p.batch > 1) kl += snprintf(key + kl, sizeof(key) - kl, ",b%d", p.batch);
   if (p.W8) kl += snprintf(key + kl, sizeof(key) - kl, ",f8");
   // problems the weight-streaming conv can take were tuned without it by older tables: their key carries a marker
-  const int ws_variant = (p.Wfr && (p.flags & GF_CONV3)) ? (dtp_conv_ws_supported(p, 0, 1) ? 0 : dtp_conv_ws_supported(p, 1, 1) ? 1 : -1) : -1;
-  if (ws_variant >= 0) snprintf(key + kl, sizeof(key) - kl, ",ws");
+  bool ws_ok[DTP_WS_VARIANTS];
+  bool ws_any = false;
+  for (int v = 0; v < DTP_WS_VARIANTS; ++v) { ws_ok[v] = p.Wfr && (p.flags & GF_CONV3) && dtp_conv_ws_supported(p, v, 1); ws_any = ws_any || ws_ok[v]; }
+  if (ws_any) snprintf(key + kl, sizeof(key) - kl, ",ws2");
   auto it = c->tuned.find(key);
   if (it != c->tuned.end() && !tune_entry_valid(p, it->second.first, it->second.second)) {
     fprintf(stderr, "[dtp] tune table entry '%s' -> (%d, %d) does not fit the problem; re-tuning\n", key, it->second.first, it->second.second);
@@ -659,14 +661,15 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
           if (ms >= 0.f) cands.push_back({ms, tile, sp});
         }
     }
-    if (ws_variant >= 0) {  // the weight-streaming conv of the small maps: K-slices = ranges of whole channel blocks
+    for (int v = 0; v < DTP_WS_VARIANTS; ++v) {  // the weight-streaming conv: K-slices = ranges of whole channel blocks
       static const bool no_ws = [] { const char* e = getenv("DTP_NO_WS"); return e && e[0] && e[0] != '0'; }();
       static const int slices[] = {1, 2, 3, 4, 5, 6, 8, 10};
       for (int sp : slices) {
-        if (no_ws || !dtp_conv_ws_supported(p, ws_variant, sp)) continue;
+        if (no_ws || !ws_ok[v] || !dtp_conv_ws_supported(p, v, sp)) continue;
+        if (v >= 2 && sp > 4) continue;
         float ms;
-        RC(time_cfg(DTP_TILE_WS0 + ws_variant, sp, 5, &ms));
-        if (ms >= 0.f) cands.push_back({ms, DTP_TILE_WS0 + ws_variant, sp});
+        RC(time_cfg(DTP_TILE_WS0 + v, sp, 5, &ms));
+        if (ms >= 0.f) cands.push_back({ms, DTP_TILE_WS0 + v, sp});
       }
     }
     // second round: the three fastest candidates are usually within the measurement noise of each other -- time them again,

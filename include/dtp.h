@@ -127,8 +127,8 @@ int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes);
  * 25-26 = gemm_wide_kernel<256,256> / <256,320> (8-wave wide tiles), 27 = gemm_fp8_kernel (all tiles),
  * 28-35 = gemm_kernel<BM,BN,NS,2> (the 8-wave twins of shapes 0..3 at 2 / 3 stages), 36-43 = gemm_kernel<BM,BN,3,1,LW> (4 / 8 loader
  * waves), 44 = xattn_kernel (fused cross-attention GEMM pair), 45-46 = conv_halo_kernel<8,8,64|128> with three images per workgroup,
- * 47 = lnlin_kernel (activation-stationary LayerNorm-folded Linear / GEGLU), 48-49 = convws_kernel (weight-streaming 3x3 conv of the
- * small maps: three 8x8 images / one 16x16 image per workgroup).  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
+ * 47 = lnlin_kernel (activation-stationary LayerNorm-folded Linear / GEGLU), 48-51 = convws_kernel (weight-streaming 3x3 conv:
+ * three 8x8 images / one 16x16 image / an 8x16 pixel tile x 64 channels per workgroup / the same for two workgroups per CU).  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
  * dtp_profile(ctx, 0) switches back to graph replay.  The nvtx/cudaEvent hooks of
  * stable_diffusion_pipeline.py:146-149,486-503 are the reference counterpart. */
 typedef struct { int kind; int launches; double ms; double flops; double bytes; } dtp_prof_row;
@@ -174,8 +174,9 @@ typedef struct {
                         workgroup (image count % 3 == 0, needs Wcb);
                         50 = lnlin_kernel: DTP_GF_LNFOLD (+ BIAS, GEGLU) with K = 320 or 640, statistics computed in-kernel
                         (st_in ignored); `splits` = column ranges per 128-row block (default 4);
-                        51 / 52 = convws_kernel (weight-streaming 3x3 conv of the small maps, needs Wfr): 51 = 8x8 images in groups
-                        of three (image count % 3 == 0), 52 = 16x16 images; stride 1, pad 1, Cin % 64 == 0 (Cin2 % 64 == 0); `splits` =
+                        51 .. 54 = convws_kernel (weight-streaming 3x3 conv, needs Wfr): 51 = 8x8 images in groups of three (image
+                        count % 3 == 0), 52 = 16x16 images, 53 = 8x16 pixel tiles of images with H % 8 == 0, W % 16 == 0 and two
+                        n-tiles (64 output channels) per workgroup, 54 = 53 built for two co-resident workgroups per CU; stride 1, pad 1, Cin % 64 == 0 (Cin2 % 64 == 0); `splits` =
                         K-slices (ranges of whole 64-channel blocks) */
   int splits;        /* 0 = heuristic; >=1 = forced split-K factor (conv_halo_kernel: slices are whole 64-channel blocks) */
   const float* lns;  /* DTP_GF_LNFOLD: row sums of the packed weights (dtp_op_rowsum) */
@@ -197,7 +198,7 @@ typedef struct {
                         [rows][ldw8] bytes, K padded to 128; with DTP_GF_LNFOLD the LayerNorm is applied while A is staged */
   int ldw8;
   float a_scale, w_scale; /* A8 = e4m3(A / a_scale), W8 = e4m3(W / w_scale) (powers of two); the product is applied to the accumulators */
-  const void* Wfr;   /* 3x3 conv, tile 51 / 52: the weights in MFMA fragment order (dtp_op_pack_conv_ws) */
+  const void* Wfr;   /* 3x3 conv, tiles 51 .. 54: the weights in MFMA fragment order (dtp_op_pack_conv_ws) */
 } dtp_gemm_desc;
 enum { DTP_GF_BIAS = 1, DTP_GF_BIAS_M = 2, DTP_GF_RESID = 4, DTP_GF_GEGLU = 8, DTP_GF_GELU = 64, DTP_GF_QUICKGELU = 128,
        DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512, DTP_GF_LNFOLD = 1024, DTP_GF_ROWSTATS = 2048, DTP_GF_SOFTMAX16 = 4096 };

@@ -354,6 +354,10 @@ WS_CASES = [
     # B, H(=W), Cin, Cout, tile (51: 8x8 images in groups of three, 52: 16x16 images), K-slices
     (3, 8, 1280, 1280, 51, 5), (3, 8, 128, 64, 51, 1), (3, 8, 192, 96, 51, 2), (6, 8, 640, 320, 51, 3), (3, 8, 2560, 1280, 51, 8),
     (3, 16, 1280, 1280, 52, 2), (1, 16, 64, 32, 52, 1), (2, 16, 320, 100, 52, 5), (3, 16, 640, 1280, 52, 1),
+    # tile 53: 8 x 16 pixel tiles (any H % 8 == 0, W % 16 == 0; here W = H or (H, W) given as a pair), two n-tiles per workgroup
+    (3, 16, 1280, 1280, 53, 2), (1, 64, 320, 320, 53, 1), (2, 32, 640, 640, 53, 2), (1, (24, 32), 128, 96, 53, 1), (3, (8, 48), 192, 160, 53, 3),
+    # tile 54: the same kernel built for two co-resident workgroups per CU (two fragment sets, the partial tiles combined one n-tile at a time)
+    (3, 16, 1280, 1280, 54, 2), (1, 64, 320, 320, 54, 1), (2, 32, 640, 640, 54, 2), (1, (24, 32), 128, 96, 54, 1), (3, (8, 48), 192, 160, 54, 3),
 ]
 
 
@@ -362,7 +366,8 @@ def test_conv3x3_weight_streaming_kernel(ops, case):
     """convws_kernel (weights in MFMA fragment order straight into registers, contraction split over the four waves) vs torch conv2d:
     split launches through the slab reduce, unsplit ones through the kernel's own bias / residual epilogue."""
     b, h, cin, cout, tile, splits = case
-    x = rnd(b, h, h, cin, seed=53)
+    h, w_ = h if isinstance(h, tuple) else (h, h)
+    x = rnd(b, h, w_, cin, seed=53)
     wt = rnd(cout, cin, 3, 3, seed=54, scale=(9 * cin) ** -0.5)
     bias = torch.randn(cout, generator=torch.Generator().manual_seed(55))
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float(), bias, padding=1).permute(0, 2, 3, 1)
@@ -374,7 +379,9 @@ def test_conv3x3_weight_streaming_kernel(ops, case):
 
 
 @pytest.mark.parametrize("b,h,cin,cin2,cout,tile,splits", [(3, 8, 1280, 2560, 1280, 51, 5), (3, 8, 128, 64, 96, 51, 1), (6, 8, 320, 448, 320, 51, 2),
-                                                           (3, 16, 1280, 1920, 1280, 52, 2), (1, 16, 64, 320, 64, 52, 1), (2, 16, 640, 640, 100, 52, 3)])
+                                                           (3, 16, 1280, 1920, 1280, 52, 2), (1, 16, 64, 320, 64, 52, 1), (2, 16, 640, 640, 100, 52, 3),
+                                                           (3, 16, 1280, 2560, 1280, 53, 2), (1, 64, 320, 960, 320, 53, 1), (2, 32, 128, 192, 96, 53, 1),
+                                                           (3, 16, 1280, 2560, 1280, 54, 2), (1, 64, 320, 960, 320, 54, 1), (2, 32, 128, 192, 96, 54, 1)])
 def test_conv3x3_weight_streaming_fused_shortcut(ops, b, h, cin, cin2, cout, tile, splits):
     """convws_kernel with the ResBlock's 1x1 shortcut: its dense blocks go from memory straight into the B-operand registers, their
     weight fragments follow the 3x3 fragments; every K-slice takes its share of both ranges (block counts that 3 does not divide)."""

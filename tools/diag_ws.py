@@ -37,7 +37,9 @@ def timeit(fn, iters=24):
 
 torch.manual_seed(0)
 TAIL = "--tail" in sys.argv     # the ResBlock tails: 3x3 conv + fused 1x1 shortcut over cin2 channels
-CASES = [(3, 8, 1280, 1280, 2560), (3, 16, 1280, 1280, 2560), (3, 16, 1280, 1280, 640)] if TAIL else \
+BIG = "--big" in sys.argv       # levels 0-1 of a batch-1 stamp (and one batch-8 shape): tile 53 against the halo tiles
+CASES = [(3, 8, 1280, 1280, 2560), (3, 16, 1280, 1280, 2560), (3, 16, 1280, 1280, 640), (3, 64, 320, 320, 960), (3, 32, 640, 640, 1920)] if TAIL else \
+    [(3, 64, 320, 320, 0), (3, 64, 640, 320, 0), (3, 64, 960, 320, 0), (3, 32, 640, 640, 0), (3, 32, 1280, 640, 0), (3, 32, 1920, 640, 0), (24, 64, 320, 320, 0)] if BIG else \
     [(3, 8, 1280, 1280, 0), (3, 8, 2560, 1280, 0), (3, 16, 1280, 1280, 0), (3, 16, 2560, 1280, 0), (3, 16, 640, 1280, 0), (3, 16, 1920, 1280, 0)]
 for b, hw, cin, cout, cin2 in CASES:
     x = torch.randn(b, hw, hw, cin, device="cuda", dtype=torch.float16)
@@ -55,13 +57,16 @@ for b, hw, cin, cout, cin2 in CASES:
     ref = ops.conv3x3(x, wp, cout, tile=6, splits=1, tail=tail).float()
     flop = 2.0 * b * hw * hw * cout * (9 * cin + cin2)
     wbytes = 2.0 * cout * (9 * cin + cin2)
-    ws = 51 if hw == 8 else 52
-    for lab, t in ([("convws", ws)] if ONLY_WS else []) or [("halo 8x8x64", 14), ("halo3 8x8x64", 48), ("halo3 8x8x128", 49), ("im2col 256x128", 17), ("convws", ws)]:
+    ws = 51 if hw == 8 else 52 if hw == 16 else 53
+    rows = [("convws", ws)] + ([("convws 8x16 nt2", 53)] if hw == 16 else []) + ([("convws nt2 2wg/cu", 54)] if hw >= 16 else [])
+    if not ONLY_WS:
+        rows = ([("halo 8x16x64", 12), ("halo 8x16x128", 13), ("im2col 256x128", 17)] if hw > 16 else [("halo 8x8x64", 14), ("halo3 8x8x64", 48), ("halo3 8x8x128", 49), ("im2col 256x128", 17)]) + rows
+    for lab, t in rows:
         r = []
-        for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
-            if t in (14, 48, 49) and (cin // 64 * 9) // sp < 9:
+        for sp in ((1, 2, 3, 4) if hw > 16 else (1, 2, 3, 4, 5, 6, 8, 10, 12, 16)):
+            if t in (12, 13, 14, 48, 49) and (cin // 64 * 9) // sp < 9:
                 continue
-            if t == ws and sp > cin // 64:
+            if t >= 51 and sp > cin // 64:
                 continue
             try:
                 got = ops.conv3x3(x, wp, cout, wcb=wcb, wfr=wfr, tile=t, splits=sp, tail=tail)
