@@ -47,12 +47,13 @@ class GemmDesc(C.Structure):
                 ("batch", C.c_int), ("a_bs", C.c_int64), ("w_bs", C.c_int64), ("c_bs", C.c_int64), ("r_bs", C.c_int64),
                 ("bias_bs", C.c_int), ("lns_bs", C.c_int), ("sm_valid", C.c_int),
                 ("st_out", C.c_void_p), ("st_in", C.c_void_p), ("st_parts", C.c_int), ("st_parts_out", C.c_int),
-                ("W8", C.c_void_p), ("ldw8", C.c_int), ("a_scale", C.c_float), ("w_scale", C.c_float), ("Wfr", C.c_void_p)]
+                ("W8", C.c_void_p), ("ldw8", C.c_int), ("a_scale", C.c_float), ("w_scale", C.c_float), ("gn_cpg", C.c_int), ("Wfr", C.c_void_p)]
 
 
 GF_BIAS, GF_BIAS_M, GF_RESID, GF_GEGLU, GF_GELU, GF_QUICKGELU, GF_OUT_F32, GF_SILU, GF_LNFOLD = 1, 2, 4, 8, 64, 128, 256, 512, 1024
 GF_SOFTMAX16 = 4096
 GF_ROWSTATS = 2048
+GF_GNSTATS = 1 << 24
 
 # every symbol include/dtp.h declares: name -> (restype, argtypes)
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -88,6 +89,7 @@ SYMBOLS = {
     "dtp_op_rowsum": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "dtp_op_quantize_w8": (_i, [_vp, _i, _i, _i, _vp, _i, C.POINTER(_f), _vp]),
     "dtp_op_pack_conv_cb": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "dtp_op_groupnorm_apply": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "dtp_op_pack_conv_ws": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "dtp_op_pack_conv_ws_elems": (C.c_longlong, [_i, _i, _i]),
     "dtp_op_groupnorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

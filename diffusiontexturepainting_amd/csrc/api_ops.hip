@@ -81,6 +81,7 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
   if (p.batch > 1) p.st_rows = p.batch * p.M;  // statistics tables are [parts][batch * M][2]
   p.W8 = (const unsigned char*)d->W8; p.ldw8 = d->ldw8; p.a_scale = d->a_scale; p.w_scale = d->w_scale;
   p.Wfr = (const f16*)d->Wfr;
+  p.gn_cpg = d->gn_cpg;
   static bool fp8_init = false;
   if (!fp8_init) { dtp_gemm_fp8_init(); fp8_init = true; }
   if (p.ldw < p.nkb * 64) { dtp_set_error("gemm: ldw=%d smaller than padded K=%d", p.ldw, p.nkb * 64); return DTP_ERR_ARG; }
@@ -169,6 +170,11 @@ int dtp_op_groupnorm(const void* x, int ldx, void* y, int ldy, const float* gamm
   if (rc) return rc;
   return dtp_launch_groupnorm((const f16*)x, ldx, (f16*)y, ldy, gamma, beta, g_ops.ws, B, HW, C, groups, eps, silu,
                               (hipStream_t)s);
+}
+
+int dtp_op_groupnorm_apply(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, const float* partial, int nchunk,
+                           int B, int HW, int C, int groups, float eps, int silu, dtp_stream s) {
+  return dtp_launch_groupnorm_apply((const f16*)x, ldx, (f16*)y, ldy, gamma, beta, partial, nchunk, B, HW, C, groups, eps, silu, (hipStream_t)s);
 }
 
 int dtp_op_reduce_groupnorm(const float* part, int splits, const float* bias, const void* resid, void* conv_out, void* y, const float* gamma,

@@ -121,6 +121,8 @@ enum {
   GF_MFAST = 1 << 20,// internal: tile_m varies fastest (neighbouring workgroups share the W panel)
   GF_NOREDUCE = 1 << 21,// internal: a split launch leaves its fp32 slabs for the consumer (fused reduce + GroupNorm)
   GF_XCDSPLIT = 1 << 23,// internal (set by the launcher): 1-D grid of tiles x splits blocks, K-slice z pinned to XCD z % 8 (see dtp_xcd_split)
+  GF_GNSTATS = 1 << 24, // convws_kernel only (unsplit, two-n-tile builds): also emit the per-(pixel tile, group) sums / sums of squares of the
+                        // rounded output for the GroupNorm that consumes it -> st_out [image][2 * tiles][N / gn_cpg][2] (conv_ws.hip)
   GF_GNAPPLY = 1 << 22, // conv_halo_kernel only: A is the RAW pre-GroupNorm tensor; the staged input patch is normalised (+ SiLU) in LDS
                         // from the statistics partials gn_part (GemmParams::gn_*): no apply launch, no normalised tensor
 };
@@ -195,7 +197,10 @@ void dtp_gemm_pick(GemmParams& p, int* tile, int num_cu);  // sets splits/kb_per
 int dtp_launch_groupnorm(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, float* stats_ws,
                          int B, int HW, int C, int groups, float eps, int silu, hipStream_t s);
 size_t dtp_groupnorm_ws_bytes(int B, int HW, int C, int groups);
-int dtp_groupnorm_stat_chunks(int HW);  // pixel chunks per sample of dtp_launch_groupnorm_stats (partials [B][chunks][groups][2])
+int dtp_groupnorm_stat_chunks(int HW);
+// the apply pass alone, on partial sums [B][nchunk][groups][2] that somebody else produced (a convws_kernel launch with GF_GNSTATS)
+int dtp_launch_groupnorm_apply(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, const float* partial, int nchunk,
+                               int B, int HW, int C, int groups, float eps, int silu, hipStream_t s);  // pixel chunks per sample of dtp_launch_groupnorm_stats (partials [B][chunks][groups][2])
 // split-K reduce (+ bias, + residual) of a conv output fused with the GroupNorm (+SiLU) that consumes it: writes the fp16 conv
 // output c_out AND the normalised tensor y -- in one launch where dtp_reduce_groupnorm_supported() (HW <= 256), otherwise the
 // reduce rides in the statistics pass of the two-launch GroupNorm (needs stats_ws, dtp_groupnorm_ws_bytes)
@@ -211,7 +216,8 @@ struct GnReduceSrc {
 // weights / biases for a grouped GEMM on the raw tensor (norm.hip gn_fold_weights_kernel)
 int dtp_launch_groupnorm_stats(const f16* x, int ldx, float* ws, int B, int HW, int C, int groups, const GnReduceSrc* rd, hipStream_t s);
 int dtp_launch_gn_fold_weights(const f16* W, int ldw, const float* bias, const float* gamma, const float* beta, const float* ws, int B, int HW,
-                               int C, int Nout, int groups, float eps, f16* Wout, long long w_bs, float* bias_out, int bias_bs, hipStream_t s);
+                               int C, int Nout, int groups, float eps, f16* Wout, long long w_bs, float* bias_out, int bias_bs, hipStream_t s,
+                               int nchunk = 0);  // nchunk > 0: ws holds that many partials per sample (not the statistics pass's own count)
 int dtp_launch_layernorm(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, int rows, int C,
                          float eps, hipStream_t s);
 int dtp_launch_softmax_rows(const f16* x, int ldx, f16* y, int ldy, int rows, int cols, float scale, hipStream_t s);

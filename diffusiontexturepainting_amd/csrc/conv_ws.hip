@@ -54,7 +54,9 @@ struct WsGeom {
   static constexpr int RPT = 32 / TW, TPI = TH / RPT;   // image rows per tile, tiles per image
   static constexpr int CBLK = 1152;                     // pitch of a 1 KB (wave, tile, register group) block of the combine area
   static constexpr int CMB = 4 * (CO ? 1 : NT) * TM * 4 * CBLK;  // the four waves' partial tiles (fp32) of one combine round
-  static constexpr int LDS = (3 * PBYTES > CMB ? 3 * PBYTES : CMB);
+  static constexpr int MAINB = (3 * PBYTES > CMB ? 3 * PBYTES : CMB);   // patches, later the combine area
+  static constexpr int STATB = (NI == 1 && NT == 2) ? (4 * NT * 32 * 2 + NT * 32 * 2) * 4 : 0;  // GF_GNSTATS: per-wave and per-workgroup channel sums
+  static constexpr int LDS = MAINB + STATB;
   static constexpr int LT = (HL - 1) / (NT * TM);       // the tap in which the last patch piece of a channel block is issued
   static constexpr int WAITB = (17 - LT) * NT;          // vmcnt at the per-block barrier (see the main loop)
   static_assert(TW == 8 || TW == 16, "pixel tile width");
@@ -117,7 +119,9 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
   // levels: 40 n-tiles, megabytes of weights per unit) the pixel groups of one unit sit next to each other on ONE XCD, whose L2
   // then serves all but the first reader of every weight fragment; otherwise (few units, many pixel groups: the wide levels, whose
   // whole weight set fits any L2) the units of one pixel group sit on one XCD and share its patches.
-  const int H = p.Hi, W = p.Wi;
+  // H x W: the map the 3x3 window slides over = the output map (stride 1); with GF_UPS2 it is the nearest-2x upsample of the stored
+  // Hi x Wi input, which only the patch DMA's source addresses know about
+  const int H = p.Ho, W = p.Wo;
   const int tiles_x = W / TW, tiles_y = H / TH;
   const int npg = (p.M / (H * W) / NI) * tiles_y * tiles_x;
   const int nts = (p.N + 31) >> 5, nrs = (nts + NT - 1) / NT, S = p.splits;
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)0x80000000u, 0x00020000);
   int voffA[HL];
   {
+    const int ups = (p.flags & GF_UPS2) ? 1 : 0;
     const int s0 = wave * 8 + (lane >> 3);  // < 32 <= HP1
     int il = 0, hy = s0 / PW, hx = s0 - hy * PW;
     constexpr int DY = 32 / PW, DX = 32 - DY * PW;
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
     for (int i = 0; i < HL; ++i) {
       const int iy = y0 + hy - 1, ix = x0 + hx - 1;
       const bool ok = il < NI && hx < TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      voffA[i] = ok ? ((((img0 + il) * H + iy) * W + ix) * p.lda + (((lane & 7) ^ (hx & 7)) << 3)) * 2 : -1;
+      voffA[i] = ok ? ((((img0 + il) * p.Hi + (iy >> ups)) * p.Wi + (ix >> ups)) * p.lda + (((lane & 7) ^ (hx & 7)) << 3)) * 2 : -1;
       hx += DX; hy += DY;
       if (hx >= PW) { hx -= PW; ++hy; }
       if (hy >= PH) { hy -= PH; ++il; }
@@ -392,6 +397,11 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
   const int epx = tid >> 3, c4 = tid & 7;            // pixel inside the tile, channel quad
   const int epxl = epx % TW, epyl = epx / TW;
   const char* const src0 = smem + (c4 >> 1) * CB + (epx * 2 + (c4 & 1)) * 16;
+  // GF_GNSTATS (unsplit launches of the two-n-tile builds): the GroupNorm that consumes this conv's output gets its statistics from
+  // here -- per (pixel tile, group) sums of the ROUNDED fp16 outputs -- instead of from a pass of its own over the tensor.
+  constexpr bool CAN_STATS = G::STATB > 0;
+  const bool stats = CAN_STATS && (p.flags & GF_GNSTATS) && p.splits == 1;
+  float* const sred = (float*)(smem + G::MAINB);     // [wave][NT * 32 channels][2], then [NT * 32][2] totals
 #pragma unroll
   for (int i0 = 0; i0 < NT; i0 += RT) {
     if (i0 > 0) __syncthreads();  // the previous round's reads are done
@@ -414,6 +424,7 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
       const bool ncol = n + 4 <= p.N;                  // N % 4 == 0 is required by the launcher
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
       if (p.splits == 1 && (p.flags & GF_BIAS) && ncol) bv = *(const f32x4*)(p.bias + n);
+      float ssum[4] = {0.f, 0.f, 0.f, 0.f}, qsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const char* src = src0 + (i * TM + j) * 4 * CB;
@@ -437,6 +448,52 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
           }
           const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
           *(f16x4*)((f16*)p.C + m * p.ldc + n) = o;
+          if constexpr (CAN_STATS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float f = (float)o[e]; ssum[e] += f; qsum[e] += f * f; }
+          }
+        }
+      }
+      if constexpr (CAN_STATS) {
+        if (stats) {  // this wave's 8 pixels (lanes 8 apart share a channel quad): fixed-order butterfly, then one writer per quad
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) { ssum[e] += __shfl_xor(ssum[e], o); qsum[e] += __shfl_xor(qsum[e], o); }
+          }
+          if (lane < 8) {
+            float* d = sred + ((wave * NT + i0 + i) * 32 + 4 * c4) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d[2 * e] = ssum[e]; d[2 * e + 1] = qsum[e]; }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (CAN_STATS) {
+    if (stats) {
+      __syncthreads();
+      float* const tot = sred + 4 * NT * 32 * 2;
+      if (tid < NT * 32 * 2) tot[tid] = ((sred[tid] + sred[NT * 64 + tid]) + sred[2 * NT * 64 + tid]) + sred[3 * NT * 64 + tid];
+      __syncthreads();
+      // partial sums [image][2 * pixel tiles][groups][2]: chunk 2 * tile + (n-range & 1).  A group overlaps one n-range (64 channels >=
+      // channels per group) or two NEIGHBOURING ones, which differ in parity: every (chunk, group) slot has exactly one writer -- the
+      // n-range that holds a group entirely also writes the zero of the other parity -- so the buffer needs no clearing.
+      const int cpg = p.gn_cpg, groups = p.N / cpg;
+      const int c_lo = nr * NT * 32, c_hi = min(p.N, c_lo + NT * 32);
+      const int g_lo = c_lo / cpg, g_hi = (c_hi - 1) / cpg;
+      const int g = g_lo + tid;
+      if (g <= g_hi) {
+        const int a = max(g * cpg, c_lo), b = min((g + 1) * cpg, c_hi);
+        float sg = 0.f, qg = 0.f;
+        for (int c = a; c < b; ++c) { sg += tot[(c - c_lo) * 2]; qg += tot[(c - c_lo) * 2 + 1]; }
+        const int ntile = tiles_x * tiles_y, pt = ty * tiles_x + tx;
+        float* const base = p.st_out + ((size_t)img0 * 2 * ntile + 2 * pt) * groups * 2;
+        float* const mine = base + (size_t)(nr & 1) * groups * 2 + g * 2;
+        mine[0] = sg; mine[1] = qg;
+        if (g * cpg >= c_lo && (g + 1) * cpg <= c_hi) {
+          float* const other = base + (size_t)((nr & 1) ^ 1) * groups * 2 + g * 2;
+          other[0] = 0.f; other[1] = 0.f;
         }
       }
     }
@@ -446,7 +503,7 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
 template <int TH, int TW, int NI, int NT, bool CO = false>
 int launch_ws(const GemmParams& p, hipStream_t s) {
   using G = WsGeom<TH, TW, NI, NT, CO>;
-  const int npg = (p.M / (p.Hi * p.Wi) / NI) * (p.Hi / TH) * (p.Wi / TW);
+  const int npg = (p.M / (p.Ho * p.Wo) / NI) * (p.Ho / TH) * (p.Wo / TW);
   const int nrs = (((p.N + 31) >> 5) + NT - 1) / NT;
   const int units = nrs * p.splits;
   const int blocks = (units & 7) == 0 ? units * npg : ((npg + 7) >> 3) * 8 * units;  // the kernel's two block -> (pixel group, unit) maps
@@ -495,22 +552,27 @@ int dtp_launch_pack_conv_ws(const float* w, const float* w1, f16* out, int Cout,
 
 // variant 0: pixel group = three 8 x 8 images (the image IS the tile), one n-tile per workgroup; variant 1: one 16 x 16 image, one
 // n-tile; variant 2: an 8 x 16 pixel tile of one image of any size (H % 8 == 0, W % 16 == 0), TWO n-tiles (64 output channels) per
-// workgroup; variant 3: variant 2 built for two co-resident workgroups per CU (WsGeom CO).  Stride 1, pad 1, Cin % 64 == 0 (and Cin2 % 64 == 0 with a fused shortcut).  nsplit K-slices (<= Cin / 64), each a
+// workgroup; variant 3: variant 2 built for two co-resident workgroups per CU (WsGeom CO).  Stride 1, pad 1 (optionally over the nearest-2x upsample of the input: GF_UPS2), Cin % 64 == 0 (and Cin2 % 64 == 0 with a fused shortcut).  nsplit K-slices (<= Cin / 64), each a
 // range of whole channel blocks; nsplit > 1 leaves fp32 slabs.
 bool dtp_conv_ws_supported(const GemmParams& p, int variant, int nsplit) {
   if (!p.Wfr || !(p.flags & GF_CONV3) || p.batch > 1) return false;
   if (p.A2 && ((p.Cin2 & 63) || (p.lda2 & 7) || (size_t)p.M * p.lda2 * 2 >= ((size_t)1 << 31))) return false;
-  if (p.flags & (GF_UPS2 | GF_GEGLU | GF_OUT_F32 | GF_LNFOLD | GF_ROWSTATS | GF_BIAS_M | GF_GELU | GF_QUICKGELU | GF_SILU | GF_GNAPPLY | GF_SOFTMAX16)) return false;
-  if (p.stride != 1 || p.pad != 1 || (p.Cin & 63) || p.Ho != p.Hi || p.Wo != p.Wi || (p.N & 3) || (p.lda & 7) || (p.ldc & 3)) return false;
+  if (p.flags & (GF_GEGLU | GF_OUT_F32 | GF_LNFOLD | GF_ROWSTATS | GF_BIAS_M | GF_GELU | GF_QUICKGELU | GF_SILU | GF_GNAPPLY | GF_SOFTMAX16)) return false;
+  if (p.stride != 1 || p.pad != 1 || (p.Cin & 63) || (p.N & 3) || (p.lda & 7) || (p.ldc & 3)) return false;
+  if (p.flags & GF_UPS2) { if (p.Ho != 2 * p.Hi || p.Wo != 2 * p.Wi) return false; }   // the window slides over the nearest-2x upsample
+  else if (p.Ho != p.Hi || p.Wo != p.Wi) return false;
   if ((p.flags & GF_RESID) && (p.ldr & 3)) return false;
-  if (p.Hi < 1 || p.Wi < 1 || p.M % (p.Hi * p.Wi)) return false;
-  const int images = p.M / (p.Hi * p.Wi);
-  if (variant == 0) { if (p.Hi != 8 || p.Wi != 8 || images % 3) return false; }
-  else if (variant == 1) { if (p.Hi != 16 || p.Wi != 16) return false; }
-  else if (variant == 2 || variant == 3) { if ((p.Hi & 7) || (p.Wi & 15)) return false; }
+  if (p.Ho < 1 || p.Wo < 1 || p.M % (p.Ho * p.Wo)) return false;
+  const int images = p.M / (p.Ho * p.Wo);
+  if (variant == 0) { if (p.Ho != 8 || p.Wo != 8 || images % 3) return false; }
+  else if (variant == 1) { if (p.Ho != 16 || p.Wo != 16) return false; }
+  else if (variant == 2 || variant == 3) { if ((p.Ho & 7) || (p.Wo & 15)) return false; }
   else return false;
+  if (p.flags & GF_GNSTATS) {  // statistics for the consuming GroupNorm: unsplit launches of the two-n-tile builds, groups of <= 64 channels
+    if (variant < 2 || nsplit != 1 || !p.st_out || p.gn_cpg < 4 || p.gn_cpg > 64 || (p.N % p.gn_cpg) || p.N / p.gn_cpg > 32) return false;
+  }
   if (nsplit < 1 || nsplit > p.Cin / 64) return false;
-  if ((size_t)p.M * p.lda * 2 >= ((size_t)1 << 31) || dtp_conv_ws_packed_elems(p.N, p.Cin, p.A2 ? p.Cin2 : 0) * 2 >= ((size_t)1 << 31)) return false;
+  if ((size_t)images * p.Hi * p.Wi * p.lda * 2 >= ((size_t)1 << 31) || dtp_conv_ws_packed_elems(p.N, p.Cin, p.A2 ? p.Cin2 : 0) * 2 >= ((size_t)1 << 31)) return false;
   return true;
 }
 

@@ -310,6 +310,7 @@ struct Builder {
   void release(const T& t);
   int gn(const T& x, const NormW& n, float eps, bool silu, T& y);
   bool claim_reduce(const T& x, GemmParams& gp, int& bias_step_off);
+  bool claim_stats(const T& x, float** partials, int* nchunk);
   bool gn_linear_supported(const T& x, const ConvW& w) const;
   int gn_linear(const T& x, const NormW& n, float eps, const ConvW& w, T& y, RowStats* emit);
   // GroupNorm + SiLU + 3x3 conv (stride 1, pad 1); the apply pass rides on the conv's staged input where the halo kernel can take it

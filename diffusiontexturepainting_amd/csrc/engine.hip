@@ -365,6 +365,31 @@ bool Builder::claim_reduce(const T& x, GemmParams& gp, int& bias_step_off) {
   return true;
 }
 
+// The producer of x was an UNSPLIT two-n-tile convws launch (tile 53 / 54): let its epilogue emit the GroupNorm partial sums of x (GF_GNSTATS,
+// conv_ws.hip) -- the consumer then needs no statistics pass over x.  Re-pushes the conv with the flag and a planned partials buffer
+// [B][nchunk][32][2]; the caller returns the buffer to the pool once its consumer is pushed.
+bool Builder::claim_stats(const T& x, float** partials, int* nchunk) {
+  static const bool off = [] { const char* e = getenv("DTP_NO_GN_EPILOGUE"); return e && e[0] && e[0] != '0'; }();
+  const LastGemm lg = prog->last_gemm;
+  const int keep = GF_BIAS | GF_RESID | GF_CONV3 | GF_UPS2 | GF_MFAST;
+  if (off || !lg.valid || lg.tile < DTP_TILE_WS0 + 2 || !dtp_is_ws_tile(lg.tile) || lg.p.splits != 1 || (f16*)lg.p.C != x.p || lg.p.ldc != x.ld ||
+      lg.p.M != (int)x.rows() || lg.p.N != x.C || (lg.p.flags & ~keep) || (x.C % 32) || x.C / 32 < 4 || x.C / 32 > 64)
+    return false;
+  GemmParams gp = lg.p;
+  const int chunks = 2 * (gp.Ho / 8) * (gp.Wo / 16);
+  void* pp = nullptr;
+  if (ctx_pool_get(c, (size_t)x.B * chunks * 32 * 2 * sizeof(float), &pp) != DTP_OK) return false;
+  gp.flags |= GF_GNSTATS;
+  gp.st_out = (float*)pp;
+  gp.gn_cpg = x.C / 32;
+  if (!dtp_conv_ws_supported(gp, lg.tile - DTP_TILE_WS0, 1)) { ctx_pool_put(c, pp); return false; }
+  prog->ops.pop_back();
+  prog_push(c, prog, lg.kind, lg.flops, lg.bytes, make_gemm_op(c, gp, lg.tile, lg.bias_step_off), lg.label + " (+gn stats)");
+  *partials = (float*)pp;
+  *nchunk = chunks;
+  return true;
+}
+
 int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
   y = alloc(x.B, x.H, x.W, x.C);
   if (!y.p) return DTP_ERR_HIP;
@@ -385,6 +410,15 @@ int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
                                          xx.p, xx.ld, yy.p, yy.ld, nn.g, nn.b, xx.B, xx.H * xx.W, xx.C, 32, eps, silu ? 1 : 0,
                                          (float*)((char*)cc->ws + slab_bytes), s);
     }, "reduce+gn B=" + std::to_string(x.B) + " HW=" + std::to_string(x.H * x.W) + " C=" + std::to_string(x.C) + " splits=" + std::to_string(gp.splits));
+    return DTP_OK;
+  }
+  float* partials = nullptr;
+  int nchunk = 0;
+  if (claim_stats(x, &partials, &nchunk)) {  // statistics from the producing conv's epilogue: the apply pass alone
+    push(PK_GN, 0.0, 4.0 * (double)xx.rows() * xx.C, [=](hipStream_t s, int) {
+      return dtp_launch_groupnorm_apply(xx.p, xx.ld, yy.p, yy.ld, nn.g, nn.b, partials, nchunk, xx.B, xx.H * xx.W, xx.C, 32, eps, silu ? 1 : 0, s);
+    }, "gn-apply B=" + std::to_string(x.B) + " HW=" + std::to_string(x.H * x.W) + " C=" + std::to_string(x.C));
+    ctx_pool_put(cc, partials);
     return DTP_OK;
   }
   push(PK_GN, 0.0, 4.0 * (double)xx.rows() * xx.C, [=](hipStream_t s, int) {
@@ -409,6 +443,9 @@ int Builder::gn_linear(const T& x, const NormW& n, float eps, const ConvW& w, T&
   GemmParams gp;
   int bso = -1;
   const bool claimed = claim_reduce(x, gp, bso);
+  float* ep_part = nullptr;  // statistics emitted by the producing conv's epilogue (claim_stats): no statistics launch at all
+  int ep_chunks = 0;
+  const bool from_epilogue = !claimed && claim_stats(x, &ep_part, &ep_chunks);
   const size_t slab_bytes = claimed ? ((dtp_gemm_workspace_bytes(gp) + 255) & ~(size_t)255) : 0;
   cc->ws_need = std::max(cc->ws_need, slab_bytes + dtp_groupnorm_ws_bytes(N, HW, C, 32));
   void *pw = nullptr, *pb = nullptr;
@@ -420,6 +457,7 @@ int Builder::gn_linear(const T& x, const NormW& n, float eps, const ConvW& w, T&
   const NormW nn = n;
   const ConvW ww = w;
   const bool has_bias = claimed && (gp.flags & GF_BIAS) != 0;
+  if (!from_epilogue)
   push(PK_GN, 0.0, 2.0 * (double)xx.rows() * C, [=](hipStream_t s, int step) {
     float* part_ws = (float*)((char*)cc->ws + slab_bytes);
     if (claimed) {
@@ -432,9 +470,11 @@ int Builder::gn_linear(const T& x, const NormW& n, float eps, const ConvW& w, T&
     return dtp_launch_groupnorm_stats(xx.p, xx.ld, part_ws, N, HW, C, 32, nullptr, s);
   }, std::string(claimed ? "reduce+gn-stats" : "gn-stats") + " B=" + std::to_string(N) + " HW=" + std::to_string(HW) + " C=" + std::to_string(C));
   push(PK_GN, 0.0, 2.0 * (double)N * w.cout * C * 2, [=](hipStream_t s, int) {
-    return dtp_launch_gn_fold_weights(ww.w, ww.ldw, ww.b, nn.g, nn.b, (const float*)((char*)cc->ws + slab_bytes), N, HW, C, ww.cout, 32, eps, Wf,
-                                      (long long)Cp * ww.ldw, bf, Cp, s);
-  }, "gn-fold B=" + std::to_string(N) + " C=" + std::to_string(C) + " N=" + std::to_string(w.cout));
+    const float* part = from_epilogue ? ep_part : (const float*)((char*)cc->ws + slab_bytes);
+    return dtp_launch_gn_fold_weights(ww.w, ww.ldw, ww.b, nn.g, nn.b, part, N, HW, C, ww.cout, 32, eps, Wf, (long long)Cp * ww.ldw, bf, Cp, s,
+                                      from_epilogue ? ep_chunks : 0);
+  }, std::string(from_epilogue ? "gn-fold (stats from conv) B=" : "gn-fold B=") + std::to_string(N) + " C=" + std::to_string(C) + " N=" + std::to_string(w.cout));
+  if (from_epilogue) ctx_pool_put(cc, ep_part);
   y = alloc(x.B, x.H, x.W, w.cout);
   if (!y.p) return DTP_ERR_HIP;
   GemmParams g = {};
@@ -763,8 +803,8 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   const int kind = dtp_is_ws_tile(tile) ? PK_WS0 + tile - DTP_TILE_WS0 : tile == DTP_TILE_LNLIN ? PK_LNLIN : tile >= 48 ? PK_HALO3 + tile - 48 : tile >= 40 ? PK_LW + tile - 40 : tile >= 32 ? PK_KH2 + tile - 32 : tile >= 24 ? PK_FP8 : tile >= 20 ? PK_WIDE0 + tile - 20 : tile >= 16 ? PK_BIG0 + tile - 16 : tile >= 12 ? PK_HALO0 + tile - 12 : PK_GEMM0 + tile;
   const double flops = 2.0 * nb * p.M * (double)p.N * k_alg;
   prog_push(c, prog, kind, flops, bytes, make_gemm_op(c, p, tile, bias_step_off), lab);
-  if (p.splits > 1) {  // a GroupNorm pushed next may take over the reduce (Builder::gn)
-    LastGemm& lg = prog->last_gemm;
+  if (p.splits > 1 || tile >= DTP_TILE_WS0 + 2) {  // a GroupNorm pushed next may take over the reduce (Builder::gn) -- or, behind an unsplit
+    LastGemm& lg = prog->last_gemm;                // two-n-tile convws launch, get its statistics from the conv's epilogue (claim_stats)
     lg.valid = true; lg.p = p; lg.tile = tile; lg.bias_step_off = bias_step_off; lg.op_index = prog->ops.size() - 1;
     lg.kind = kind; lg.flops = flops; lg.bytes = bytes; lg.label = lab;
   }

@@ -620,6 +620,21 @@ static int groupnorm_two_pass(const f16* x, int ldx, f16* y, int ldy, const floa
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
+int dtp_launch_groupnorm_apply(const f16* x, int ldx, f16* y, int ldy, const float* gamma, const float* beta, const float* partial, int nchunk,
+                               int B, int HW, int C, int groups, float eps, int silu, hipStream_t s) {
+  if ((C & 7) || (C % groups) || (ldx & 7) || (ldy & 7) || groups > 32 || nchunk < 1 || C / groups < 4 || (C / groups < 8 && C / groups != 4)) {
+    dtp_set_error("groupnorm apply: C=%d groups=%d ldx=%d ldy=%d nchunk=%d unsupported", C, groups, ldx, ldy, nchunk);
+    return DTP_ERR_ARG;
+  }
+  const long long per_batch = (long long)HW * (C / 8);
+  long long bx = (per_batch + 1023) / 1024;
+  const long long cap = std::max<long long>(1, 256 / B);
+  if (bx > cap) bx = cap;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((int)bx, B), dim3(1024), 0, s, x, ldx, y, ldy, gamma, beta, partial, nchunk, HW, C, C / groups, groups, silu,
+                     1.0f / ((float)HW * (C / groups)), eps);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
+
 // statistics pass alone (partial sums -> ws), optionally with the producing conv's split-K reduce folded in (rd): first half of
 // GroupNorm-folded-into-its-Linear (gn_fold_weights_kernel)
 int dtp_launch_groupnorm_stats(const f16* x, int ldx, float* ws, int B, int HW, int C, int groups, const GnReduceSrc* rd, hipStream_t s) {
@@ -644,12 +659,12 @@ int dtp_launch_groupnorm_stats(const f16* x, int ldx, float* ws, int B, int HW, 
 
 // second half: per-sample weights W diag(a_b) and biases bias + W d_b from the partial sums `ws` of dtp_launch_groupnorm_stats
 int dtp_launch_gn_fold_weights(const f16* W, int ldw, const float* bias, const float* gamma, const float* beta, const float* ws, int B, int HW,
-                               int C, int Nout, int groups, float eps, f16* Wout, long long w_bs, float* bias_out, int bias_bs, hipStream_t s) {
+                               int C, int Nout, int groups, float eps, f16* Wout, long long w_bs, float* bias_out, int bias_bs, hipStream_t s, int nchunk) {
   if ((C & 7) || C > 2048 || (C % groups) || groups > 32 || (ldw & 7) || C / 8 > 256) {
     dtp_set_error("gn fold: C=%d groups=%d ldw=%d unsupported", C, groups, ldw);
     return DTP_ERR_ARG;
   }
-  hipLaunchKernelGGL(gn_fold_weights_kernel, dim3((Nout + 7) / 8, B), dim3(256), 0, s, W, ldw, bias, gamma, beta, ws, gn_chunks(HW), C, C / groups, groups,
+  hipLaunchKernelGGL(gn_fold_weights_kernel, dim3((Nout + 7) / 8, B), dim3(256), 0, s, W, ldw, bias, gamma, beta, ws, nchunk > 0 ? nchunk : gn_chunks(HW), C, C / groups, groups,
                      1.0f / ((float)HW * (C / groups)), eps, Nout, Wout, w_bs, bias_out, bias_bs);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }

@@ -130,7 +130,7 @@ def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, ou
 
 
 def conv3x3(x, wp, cout, stride=1, pad=1, upsample=False, bias=None, resid=None, tile=-1, splits=0, out_hw=None, flags=0,
-            tail=None, wcb=None, wfr=None):
+            tail=None, wcb=None, wfr=None, gn_groups=0):
     """x f16 NHWC [B,H,W,C] -> f16 NHWC [B,Ho,Wo,cout].  pad is the top/left zero padding; bottom/right
     padding is implied by out_hw (default: the symmetric-padding output size)."""
     lib = _lib.load()
@@ -154,8 +154,13 @@ def conv3x3(x, wp, cout, stride=1, pad=1, upsample=False, bias=None, resid=None,
         d.Wcb = wcb.data_ptr()
     if wfr is not None:
         d.Wfr = wfr.data_ptr()
+    st = None
+    if gn_groups:  # tiles 53 / 54, unsplit: also return the GroupNorm partial sums f32 [B, 2 * tiles, groups, 2] of the output
+        st = torch.full((b, 2 * (ho // 8) * (wo // 16), gn_groups, 2), float("nan"), dtype=torch.float32, device=x.device)
+        d.st_out, d.gn_cpg = st.data_ptr(), cout // gn_groups
+        d.flags |= _lib.GF_GNSTATS
     check(lib.dtp_op_gemm(C.byref(d), _stream()), "conv3x3")
-    return out
+    return (out, st) if gn_groups else out
 
 
 def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False):
@@ -166,6 +171,17 @@ def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False):
     y = torch.empty_like(x)
     check(lib.dtp_op_groupnorm(ptr(x), c, ptr(y), c, ptr(gamma), ptr(beta), b, hw, c, groups, eps, int(silu), _stream()),
           "groupnorm")
+    return y
+
+
+def groupnorm_apply(x, gamma, beta, partial, groups=32, eps=1e-5, silu=False):
+    """GroupNorm of x f16 [B,H,W,C] from producer-emitted partial sums f32 [B, nchunk, groups, 2] (no statistics pass)."""
+    lib = _lib.load()
+    b, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (b * c)
+    y = torch.empty_like(x)
+    check(lib.dtp_op_groupnorm_apply(ptr(x), c, ptr(y), c, ptr(gamma), ptr(beta), ptr(partial), partial.shape[1], b, hw, c, groups, eps, int(silu),
+                                     _stream()), "groupnorm_apply")
     return y
 
 

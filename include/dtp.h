@@ -198,10 +198,14 @@ typedef struct {
                         [rows][ldw8] bytes, K padded to 128; with DTP_GF_LNFOLD the LayerNorm is applied while A is staged */
   int ldw8;
   float a_scale, w_scale; /* A8 = e4m3(A / a_scale), W8 = e4m3(W / w_scale) (powers of two); the product is applied to the accumulators */
+  int gn_cpg;        /* DTP_GF_GNSTATS (tiles 53 / 54, unsplit): channels per group of the GroupNorm that consumes the output; st_out then
+                        receives f32 [images][2 * (Ho/8) * (Wo/16)][N / gn_cpg][2] partial (sum, sum of squares) of the rounded outputs,
+                        the input of dtp_op_groupnorm_apply */
   const void* Wfr;   /* 3x3 conv, tiles 51 .. 54: the weights in MFMA fragment order (dtp_op_pack_conv_ws) */
 } dtp_gemm_desc;
 enum { DTP_GF_BIAS = 1, DTP_GF_BIAS_M = 2, DTP_GF_RESID = 4, DTP_GF_GEGLU = 8, DTP_GF_GELU = 64, DTP_GF_QUICKGELU = 128,
-       DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512, DTP_GF_LNFOLD = 1024, DTP_GF_ROWSTATS = 2048, DTP_GF_SOFTMAX16 = 4096 };
+       DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512, DTP_GF_LNFOLD = 1024, DTP_GF_ROWSTATS = 2048, DTP_GF_SOFTMAX16 = 4096,
+       DTP_GF_GNSTATS = 1 << 24 };
 
 int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s);
 /* w f32 [N][K] -> out f16 [rows][ldw] (caller zero-fills out); geglu=1 applies the [a|gate] tile packing */
@@ -222,6 +226,10 @@ int dtp_op_pack_conv_ws(const float* w, const float* w1, void* out, int Cout, in
 long long dtp_op_pack_conv_ws_elems(int Cout, int Cin, int Cin2);
 int dtp_op_groupnorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
                      int groups, float eps, int silu, dtp_stream s);
+/* the apply pass of the two-launch GroupNorm on partial sums f32 [B][nchunk][groups][2] that a producer emitted (a convws_kernel launch
+ * with DTP_GF_GNSTATS): y = GroupNorm(x) (+SiLU) without a statistics pass over x */
+int dtp_op_groupnorm_apply(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, const float* partial, int nchunk,
+                           int B, int HW, int C, int groups, float eps, int silu, dtp_stream s);
 /* measured ceilings of this GPU (bench.py roofline.peak_measured): dense fp16 MFMA TFLOP/s with random operands on every SIMD, and
  * the HBM GB/s (read + write) of a 512 MiB float4 copy; blocking, ~50 ms */
 int dtp_op_measure_peaks(double* mfma_f16_tflops, double* hbm_copy_gbs);

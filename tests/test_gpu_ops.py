@@ -378,6 +378,44 @@ def test_conv3x3_weight_streaming_kernel(ops, case):
     close(got, ref)
 
 
+@pytest.mark.parametrize("b,h,cin,cout,tile,resid", [(3, 64, 320, 320, 54, False), (2, 32, 640, 640, 53, True), (1, (16, 32), 128, 1280, 54, True),
+                                                     (2, 16, 64, 640, 53, False)])
+def test_conv3x3_weight_streaming_emits_groupnorm_statistics(ops, b, h, cin, cout, tile, resid):
+    """DTP_GF_GNSTATS: the conv's epilogue also emits per-(pixel tile, group) sums of its rounded outputs (32 groups of 10 / 20 / 40
+    channels: groups straddle the 64-channel n-ranges); summed over the chunks they are the statistics of the stored tensor, and the
+    apply pass fed with them equals torch's group_norm."""
+    h, w_ = h if isinstance(h, tuple) else (h, h)
+    x = rnd(b, h, w_, cin, seed=83)
+    wt = rnd(cout, cin, 3, 3, seed=84, scale=(9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(85))
+    res = rnd(b, h, w_, cout, seed=86) if resid else None
+    wf = wt.float().cuda()
+    y, st = ops.conv3x3(x.cuda(), ops.pack_conv(wf), cout, bias=bias.cuda(), resid=res.cuda() if resid else None, wfr=ops.pack_conv_ws(wf), tile=tile,
+                        splits=1, gn_groups=32)
+    assert torch.isfinite(st).all()  # every (chunk, group) slot was written
+    yf = y.float().reshape(b, h * w_, 32, cout // 32)
+    want = torch.stack([yf.sum(dim=(1, 3)), (yf * yf).sum(dim=(1, 3))], dim=-1)
+    got = st.sum(dim=1)
+    assert torch.allclose(got, want, rtol=2e-4, atol=2e-2), (got - want).abs().max().item()
+    gamma, beta = torch.randn(cout, generator=torch.Generator().manual_seed(87)).cuda(), torch.randn(cout, generator=torch.Generator().manual_seed(88)).cuda()
+    z = ops.groupnorm_apply(y, gamma, beta, st, eps=1e-5, silu=True)
+    ref = F.silu(F.group_norm(y.float().permute(0, 3, 1, 2), 32, gamma, beta, eps=1e-5)).permute(0, 2, 3, 1)
+    close(z, ref.cpu())
+
+
+@pytest.mark.parametrize("b,h,cin,cout,tile,splits", [(3, 8, 1280, 1280, 52, 2), (3, 4, 128, 64, 51, 1), (3, 16, 1280, 1280, 54, 1), (1, 32, 640, 640, 53, 1), (2, 8, 192, 96, 54, 3)])
+def test_conv3x3_weight_streaming_upsample(ops, b, h, cin, cout, tile, splits):
+    """convws_kernel over the nearest-2x upsample of the stored input (the Upsample2D conv): only the patch DMA's addresses change."""
+    x = rnd(b, h, h, cin, seed=73)
+    wt = rnd(cout, cin, 3, 3, seed=74, scale=(9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(75))
+    xin = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, wt.float(), bias, padding=1).permute(0, 2, 3, 1)
+    wf = wt.float().cuda()
+    got = ops.conv3x3(x.cuda(), ops.pack_conv(wf), cout, upsample=True, bias=bias.cuda(), wfr=ops.pack_conv_ws(wf), tile=tile, splits=splits)
+    close(got, ref)
+
+
 @pytest.mark.parametrize("b,h,cin,cin2,cout,tile,splits", [(3, 8, 1280, 2560, 1280, 51, 5), (3, 8, 128, 64, 96, 51, 1), (6, 8, 320, 448, 320, 51, 2),
                                                            (3, 16, 1280, 1920, 1280, 52, 2), (1, 16, 64, 320, 64, 52, 1), (2, 16, 640, 640, 100, 52, 3),
                                                            (3, 16, 1280, 2560, 1280, 53, 2), (1, 64, 320, 960, 320, 53, 1), (2, 32, 128, 192, 96, 53, 1),
