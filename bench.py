@@ -21,6 +21,7 @@ import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 import torch
@@ -268,6 +269,36 @@ def launch_ranks(a, argv):
                 pass
 
 
+def launch_classes(path):
+    """Per-launch table of the profiled stamp (dtp_profile_dump: kind, us, tflops, algo_GBps, label) aggregated by output-row count M of
+    the contraction launches (conv3 / gemm / xattn; the batch-1 levels of the UNet are M = 12288 / 3072 / 768 / 192), plus the
+    GroupNorm launches of the small maps and the count of stand-alone split-K reduce launches (a split launch whose reduce does not
+    ride in a GroupNorm kernel)."""
+    import csv
+    import re
+    by_m, small_gn, big_gn, standalone = {}, [0, 0.0], [0, 0.0], 0
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            lab, us, tf = r["label"], float(r["us"]), float(r["tflops"])
+            m = re.match(r"(conv3|gemm|xattn) M=(\d+)", lab)
+            if m:
+                rows = int(m.group(2)) * (int(re.search(r" x(\d+)", lab).group(1)) if re.search(r" x(\d+)", lab) else 1)
+                c = by_m.setdefault(rows, [0, 0.0, 0.0])
+                c[0] += 1; c[1] += us; c[2] += tf * us
+                sp = re.search(r"splits=(\d+)", lab)
+                if sp and int(sp.group(1)) > 1 and "tile=50" not in lab and "reduce in gn" not in lab:
+                    standalone += 1
+            elif "gn" in lab:
+                hw = re.search(r"HW=(\d+)", lab)
+                tgt = small_gn if hw and int(hw.group(1)) <= 256 else big_gn
+                tgt[0] += 1; tgt[1] += us
+    return {"m_classes": [{"M": k, "launches": v[0], "ms": round(v[1] / 1e3, 3), "tflops": round(v[2] / v[1], 1) if v[1] else 0.0}
+                          for k, v in sorted(by_m.items(), key=lambda kv: -kv[1][1])[:12]],
+            "groupnorm_small_maps": {"launches": small_gn[0], "ms": round(small_gn[1] / 1e3, 3)},
+            "groupnorm_large_maps": {"launches": big_gn[0], "ms": round(big_gn[1] / 1e3, 3)},
+            "standalone_splitk_reduce_launches": standalone}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -359,8 +390,11 @@ def main():
         model.profile(True)
         model._stamp(canvas, settings, composite=True, latents=lat, vae_eps=eps, output_u8=True)
         rows = model.profile_rows()
-        if a.dump_launches:
-            model.profile_dump(a.dump_launches)
+        dump_path = a.dump_launches or os.path.join(tempfile.gettempdir(), f"dtp_launches_{os.getpid()}.csv")
+        model.profile_dump(dump_path)
+        classes = launch_classes(dump_path)
+        if not a.dump_launches:
+            os.unlink(dump_path)
         model.profile(False)
         tot_ms = sum(r["ms"] for r in rows)
         gem = [r for r in rows if r["kernel"].startswith(("gemm_kernel", "conv_halo_kernel", "gemm_wide_kernel", "xattn_kernel", "lnlin_kernel", "convws_kernel"))]
@@ -378,6 +412,7 @@ def main():
             "launches": g_n, "avg_launch_us": g_ms * 1e3 / g_n, "share_of_gpu_time": g_ms / tot_ms,
             "algorithmic_tflop_per_step": g_fl / 1e12,
             "algorithmic_bytes_per_launch": sum(r["bytes"] for r in gem) / g_n,
+            **classes,
             **pmc_traffic(a.batch),
             "dominant_instantiation": {"kernel": dom["kernel"], "launches": dom["launches"],
                                        "avg_launch_us": dom["ms"] * 1e3 / dom["launches"],

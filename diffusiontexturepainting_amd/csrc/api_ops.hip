@@ -108,6 +108,7 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
     int bm = 0, bn = 64, ns = 0;
     (void)dtp_gemm_tile_dims(tile, &bm, &bn, &ns);
     d->st_parts_out = p.splits > 1 ? 1 : (p.N + bn - 1) / bn;
+    if (tile == DTP_TILE_LNLIN) d->st_parts_out = d->splits >= 1 ? d->splits : 4;  // one partial per column range
   }
   if (tile == DTP_TILE_LNLIN) return dtp_launch_lnlin(p, d->splits >= 1 ? d->splits : 4, (hipStream_t)s);
   if (dtp_is_halo_tile(tile)) return dtp_launch_conv_halo(p, dtp_halo_variant(tile), (hipStream_t)s);

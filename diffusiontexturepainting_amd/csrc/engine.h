@@ -211,7 +211,7 @@ struct Ctx {
   ImgEncW ienc;
 
   // programs keyed by batch
-  std::map<int, UNetProg> unet_progs;  // key = N * 64 + dupB (dupB = samples filled by duplication, 0 = none)
+  std::map<int, UNetProg> unet_progs;  // key = N * 128 + dupB (dupB = samples filled by duplication, 0 = none)
   std::map<int, VaeEncProg> enc_progs;
   std::map<int, VaeDecProg> dec_progs;
 

@@ -356,6 +356,10 @@ bool Builder::claim_reduce(const T& x, GemmParams& gp, int& bias_step_off) {
   if (!(c->fuse_reduce_gn && lg.valid && lg.p.splits > 1 && (f16*)lg.p.C == x.p && lg.p.ldc == x.ld && lg.p.M == (int)x.rows() && lg.p.N == x.C &&
         !(lg.p.flags & ~keep) && lg.p.batch <= 1 && (x.C & 7) == 0))
     return false;
+  {  // what the GroupNorm-side reduce kernels accept (norm.hip): checked here, where the separate reduce is still the fallback
+    const int cpg = x.C / 32;
+    if ((x.C % 32) || cpg < 4 || (cpg < 8 && cpg != 4) || (lg.p.N & 3) || x.C / 8 > 1024 || (x.ld & 7) || ((lg.p.flags & GF_RESID) && (lg.p.ldr & 7))) return false;
+  }
   gp = lg.p;
   gp.flags |= GF_NOREDUCE;
   prog->ops[lg.op_index] = Op();  // rebuilt below through the profiling wrapper
@@ -580,7 +584,13 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   bool ws_ok[DTP_WS_VARIANTS];
   bool ws_any = false;
   for (int v = 0; v < DTP_WS_VARIANTS; ++v) { ws_ok[v] = p.Wfr && (p.flags & GF_CONV3) && dtp_conv_ws_supported(p, v, 1); ws_any = ws_any || ws_ok[v]; }
-  if (ws_any) snprintf(key + kl, sizeof(key) - kl, ",ws2");
+  if (ws_any) kl += snprintf(key + kl, sizeof(key) - kl, ",ws2");
+  // ... and so do the plain problems the activation-stationary Linear takes since round 4 (attention output projection, grouped proj_in)
+  if (!(p.flags & GF_LNFOLD)) {
+    bool ll = false;
+    for (int r = 1; r <= 40 && !ll; ++r) ll = dtp_lnlin_supported(p, r);
+    if (ll) snprintf(key + kl, sizeof(key) - kl, ",ll");
+  }
   auto it = c->tuned.find(key);
   if (it != c->tuned.end() && !tune_entry_valid(p, it->second.first, it->second.second)) {
     fprintf(stderr, "[dtp] tune table entry '%s' -> (%d, %d) does not fit the problem; re-tuning\n", key, it->second.first, it->second.second);
@@ -784,7 +794,7 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
   if (emit) {  // the consumer must know how many partials this launch configuration writes per row
     int bm = 0, bn = 128, ns = 0;
     (void)dtp_gemm_tile_dims(tile, &bm, &bn, &ns);
-    emit->parts = p.splits > 1 ? 1 : (p.N + bn - 1) / bn;
+    emit->parts = tile == DTP_TILE_LNLIN ? p.col_ranges : p.splits > 1 ? 1 : (p.N + bn - 1) / bn;
     emit->M = p.M * (p.batch > 1 ? p.batch : 1);
   }
   c->ws_need = std::max(c->ws_need, dtp_gemm_workspace_bytes(p));

@@ -37,8 +37,14 @@ constexpr int VEC_BYTES = MAX_CHUNKS * 4 * 32 * 4;  // [chunk][la | ba | lg | bg
 constexpr int LNLIN_LDS = 3 * UNIT_BYTES + 4 * STG_BYTES + VEC_BYTES;
 
 // KU: K / 320.  GEGLU: chunk = a/g row pair.  p.splits = column ranges (workgroups per 128-row block).
-template <int KU, bool GEGLU>
+// LN = false (round 4): the same activation-stationary stream WITHOUT the LayerNorm -- out = A W^T + bias (+ R) -- for the other
+// short contractions of the transformer blocks at levels 0-1: the attention output projection (K = N = C, + residual, + the row
+// statistics the next LayerNorm-folded GEMM wants: GF_ROWSTATS, one partial per column range) and proj_in as a grouped problem
+// (p.batch samples of M rows, per-sample weights / biases: the GroupNorm folded into them).  The residual is added and the
+// statistics are taken in the transposed store phase, where a lane holds 16 bytes of one output row.
+template <int KU, bool GEGLU, bool LN = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void lnlin_kernel(const GemmParams p) {  // two workgroups per CU: <= 256 registers
+  static_assert(LN || !GEGLU, "the plain variant has no GEGLU epilogue");
   constexpr int K = KU * 320, NKB = K / 64, KST = K / 16;  // k-blocks, k-steps of the whole contraction
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;
@@ -51,19 +57,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
 
   // workgroups of one row block share an XCD (block b runs on XCD b % 8): the block's activations are fetched into one L2
   const int nsplit = p.splits;
-  const int rblocks = (p.M + 127) >> 7;
+  const int Mtot = p.M * (p.batch > 1 ? p.batch : 1);  // grouped problems: sample b = rows [b M, (b + 1) M), M % 128 == 0
+  const int rblocks = (Mtot + 127) >> 7;
   const int b = blockIdx.x;
   const int split = (b >> 3) % nsplit;
   const int rb = (b & 7) + 8 * (b / (8 * nsplit));
   if (rb >= rblocks) return;
   const int m0 = rb * 128;
+  const int smp = p.batch > 1 ? m0 / p.M : 0;  // sample of this row block
   const int nchunks_all = GEGLU ? (p.N >> 6) : (p.N >> 5);  // 32-column output chunks
   const int cper = (nchunks_all + nsplit - 1) / nsplit;
   const int c0 = split * cper, c1 = min(c0 + cper, nchunks_all);
   if (c0 >= c1) return;
 
   constexpr int OOB = (int)0x80000000u;
-  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, OOB, 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)smp * p.w_bs), 0, OOB, 0x00020000);
+  const float* const bias = p.bias ? p.bias + (size_t)smp * p.bias_bs : nullptr;
 
   // ---- per-chunk vectors of this column range -> LDS (read back in the epilogues)
   {
@@ -72,11 +81,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
       const int c = i >> 5, j = i & 31, cg = c0 + c;
       const int ra = GEGLU ? (cg >> 1) * 128 + (cg & 1) * 32 + j : cg * 32 + j;  // packed weight row of output column j of the chunk
       float* v = vecs + c * 128;
-      v[j] = p.lns[ra];
-      v[32 + j] = (p.flags & GF_BIAS) ? p.bias[ra] : 0.f;
+      v[j] = LN ? p.lns[ra] : 0.f;
+      v[32 + j] = (p.flags & GF_BIAS) ? bias[ra] : 0.f;
       if constexpr (GEGLU) {
         v[64 + j] = p.lns[ra + 64];
-        v[96 + j] = (p.flags & GF_BIAS) ? p.bias[ra + 64] : 0.f;
+        v[96 + j] = (p.flags & GF_BIAS) ? bias[ra + 64] : 0.f;
       }
     }
   }
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     for (int i = 0; i < 4; ++i) {
       const int r = i * 32 + wave * 8 + (lane >> 3);
       const int m = m0 + r;
-      voffA[i] = (m < p.M) ? (m * p.lda + (((lane & 7) ^ ((r >> 1) & 7)) << 3)) * 2 : OOB;
+      voffA[i] = (m < Mtot) ? (m * p.lda + (((lane & 7) ^ ((r >> 1) & 7)) << 3)) * 2 : OOB;
     }
     auto issue_a = [&](int kb) {
       char* dst = smem + (kb & 3) * 16384;
@@ -125,8 +134,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     }
   }
   // LayerNorm statistics of this lane's row from the resident fragments (each half-wave holds alternate 8-element chunks)
-  float mean, rstd;
-  {
+  float mean = 0.f, rstd = 1.f;
+  if constexpr (LN) {
     float s1 = 0.f, s2 = 0.f;
     const f16x2 one2 = {(f16)1.f, (f16)1.f};
 #pragma unroll
@@ -216,6 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
   };
   typedef std::integral_constant<int, 0> I0;
   typedef std::integral_constant<int, 1> I1;
+  float rs1[2] = {0.f, 0.f}, rs2[2] = {0.f, 0.f};  // LN = false, GF_ROWSTATS: (sum, sum of squares) of this lane's two output rows
   for (int cl = 0; cl < c1 - c0; ++cl) {
     unit(I0{}, I0{});
     if constexpr (KU == 2) unit(I0{}, I1{});
@@ -239,9 +249,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
             const float gv = rstd * (acc_g[4 * q + e] - mean * lg[e]) + bg[e];
             o[e] = (f16)(av * gelu_erf(gv));
           }
-        } else {
+        } else if constexpr (LN) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (f16)(rstd * (acc_a[4 * q + e] - mean * la[e]) + ba[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (f16)(acc_a[4 * q + e] + ba[e]);
         }
         *(f16x4*)(stg + mrow * STG_LD + j * 2) = o;
       }
@@ -253,18 +266,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
       for (int rr = 0; rr < 2; ++rr) {
         const int row = (lane >> 2) + 16 * rr, cc = lane & 3;
         const int m = m0 + wave * 32 + row;
-        const f16x8 ov = *(const f16x8*)(stg + row * STG_LD + cc * 16);
-        if (m < p.M) *(f16x8*)((f16*)p.C + (size_t)m * p.ldc + ncol + cc * 8) = ov;
+        f16x8 ov = *(const f16x8*)(stg + row * STG_LD + cc * 16);
+        if constexpr (!LN) {
+          if (p.flags & GF_RESID) {  // (like gemm_kernel: the staged fp16 value + the residual, rounded again)
+            const f16x8 rv = *(const f16x8*)(p.R + (size_t)min(m, Mtot - 1) * p.ldr + ncol + cc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (f16)((float)ov[e] + (float)rv[e]);
+          }
+          if (p.flags & GF_ROWSTATS) {  // statistics of the stored values: four lanes hold one row's 32 columns of this chunk
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)ov[e]; s1 += f; s2 += f * f; }
+            s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
+            s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+            rs1[rr] += s1; rs2[rr] += s2;
+          }
+        }
+        if (m < Mtot) *(f16x8*)((f16*)p.C + (size_t)m * p.ldc + ncol + cc * 8) = ov;
+      }
+    }
+  }
+  if constexpr (!LN) {
+    if ((p.flags & GF_ROWSTATS) && (lane & 3) == 0) {  // one partial per column range: st_out [range][st_rows][2]
+      const int st_rows = p.st_rows > 0 ? p.st_rows : Mtot;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int m = m0 + wave * 32 + (lane >> 2) + 16 * rr;
+        if (m < Mtot) {
+          float* d = p.st_out + ((size_t)split * st_rows + m) * 2;
+          d[0] = rs1[rr]; d[1] = rs2[rr];
+        }
       }
     }
   }
 }
 
-template <int KU, bool GEGLU>
+template <int KU, bool GEGLU, bool LN = true>
 int launch(const GemmParams& p, hipStream_t s) {
-  const int rblocks = (p.M + 127) >> 7;
+  const int rblocks = (p.M * (p.batch > 1 ? p.batch : 1) + 127) >> 7;
   const int blocks = ((rblocks + 7) / 8) * 8 * p.splits;
-  hipLaunchKernelGGL((lnlin_kernel<KU, GEGLU>), dim3(blocks), dim3(256), LNLIN_LDS, s, p);
+  hipLaunchKernelGGL((lnlin_kernel<KU, GEGLU, LN>), dim3(blocks), dim3(256), LNLIN_LDS, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
@@ -275,21 +316,31 @@ void dtp_lnlin_init() {
   (void)hipFuncSetAttribute((const void*)lnlin_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
   (void)hipFuncSetAttribute((const void*)lnlin_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
   (void)hipFuncSetAttribute((const void*)lnlin_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
+  (void)hipFuncSetAttribute((const void*)lnlin_kernel<1, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
+  (void)hipFuncSetAttribute((const void*)lnlin_kernel<2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
 }
 
-// Dense, unbatched, LayerNorm-folded (in-kernel statistics: st_in is not needed and ignored), K = 320 or 640, fp16 output, optional
-// bias / GEGLU, nothing else in the epilogue.  p.splits (1..): column ranges per 128-row block, at most MAX_CHUNKS chunks each.
+// Dense, K = 320 or 640, fp16 output.  Either LayerNorm-folded (GF_LNFOLD: in-kernel statistics, st_in is not needed and ignored;
+// unbatched; optional bias / GEGLU, nothing else in the epilogue) or plain (round 4: bias / residual / row statistics; optionally a
+// grouped problem of p.batch samples with M % 128 == 0 rows each and per-sample weights / biases, rows and statistics indexed
+// by the global row).  nsplit (1..): column ranges per 128-row block, at most MAX_CHUNKS chunks each.
 bool dtp_lnlin_supported(const GemmParams& p, int nsplit) {
-  const int allowed = GF_LNFOLD | GF_BIAS | GF_GEGLU | GF_MFAST;
-  if (!(p.flags & GF_LNFOLD) || (p.flags & ~allowed) || !p.lns || p.W8 || p.A2 || p.batch > 1) return false;
+  const bool ln = (p.flags & GF_LNFOLD) != 0;
+  const int allowed = ln ? (GF_LNFOLD | GF_BIAS | GF_GEGLU | GF_MFAST) : (GF_BIAS | GF_RESID | GF_ROWSTATS | GF_MFAST);
+  if ((p.flags & ~allowed) || p.W8 || p.A2 || (ln && (!p.lns || p.batch > 1))) return false;
   if (p.K != 320 && p.K != 640) return false;
   if ((p.lda & 7) || (p.ldw & 7) || (p.ldc & 7) || p.ldw < p.K) return false;
   const bool geglu = (p.flags & GF_GEGLU) != 0;
   if (geglu ? (p.N & 127) : (p.N & 31)) return false;
-  if ((size_t)p.M * p.lda * 2 >= ((size_t)1 << 31) || ((size_t)p.N + 128) * p.ldw * 2 >= ((size_t)1 << 31)) return false;
+  const int nb = p.batch > 1 ? p.batch : 1;
+  if (nb > 1 && ((p.M & 127) || p.a_bs != (long long)p.M * p.lda || p.c_bs != (long long)p.M * p.ldc || ((p.flags & GF_RESID) && p.r_bs != (long long)p.M * p.ldr))) return false;
+  if ((p.flags & GF_RESID) && (!p.R || (p.ldr & 7))) return false;
+  if ((p.flags & GF_ROWSTATS) && !p.st_out) return false;
+  if ((size_t)p.M * nb * p.lda * 2 >= ((size_t)1 << 31) || ((size_t)p.N + 128) * p.ldw * 2 >= ((size_t)1 << 31)) return false;
   if (nsplit < 1) return false;
   const int nch = geglu ? (p.N >> 6) : (p.N >> 5);
   if (nsplit > nch || (nch + nsplit - 1) / nsplit > MAX_CHUNKS) return false;
+  if ((p.flags & GF_ROWSTATS) && nsplit > (p.N + 63) / 64) return false;  // the consumer's table has room for one partial per 64 columns
   return true;
 }
 
@@ -297,9 +348,10 @@ int dtp_launch_lnlin(const GemmParams& pin, int nsplit, hipStream_t s) {
   if (!dtp_lnlin_supported(pin, nsplit)) { dtp_set_error("lnlin: unsupported problem (M %d N %d K %d flags %#x, %d column ranges)", pin.M, pin.N, pin.K, pin.flags, nsplit); return DTP_ERR_ARG; }
   GemmParams p = pin;
   p.splits = nsplit;
-  const bool geglu = (p.flags & GF_GEGLU) != 0;
+  const bool geglu = (p.flags & GF_GEGLU) != 0, ln = (p.flags & GF_LNFOLD) != 0;
   int rc;
-  if (p.K == 320) rc = geglu ? launch<1, true>(p, s) : launch<1, false>(p, s);
+  if (!ln) rc = p.K == 320 ? launch<1, false, false>(p, s) : launch<2, false, false>(p, s);
+  else if (p.K == 320) rc = geglu ? launch<1, true>(p, s) : launch<1, false>(p, s);
   else rc = geglu ? launch<2, true>(p, s) : launch<2, false>(p, s);
   if (rc != DTP_OK) dtp_set_error("lnlin launch failed: %s", hipGetErrorString(hipGetLastError()));
   return rc;

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void gn_fold_weights_kernel(const f16* __restr
                                                               float inv_count, float eps, int Nout, f16* __restrict__ Wout, long long w_bs,
                                                               float* __restrict__ bias_out, int bias_bs) {
   __shared__ float st[64 * 2];
-  __shared__ float ad[2][2048];
+  __shared__ float ad[3][2048];  // a_b[c], beta[c], mean of c's group
   __shared__ float red[256];
   const int b = blockIdx.y, tid = threadIdx.x;
   {
@@ -439,7 +439,8 @@ __global__ __launch_bounds__(256) void gn_fold_weights_kernel(const f16* __restr
     const int g = c / cpg;
     const float a = gamma[c] * st[g * 2 + 1];
     ad[0][c] = a;
-    ad[1][c] = beta[c] - st[g * 2] * a;
+    ad[1][c] = beta[c];
+    ad[2][c] = st[g * 2];
   }
   __syncthreads();
   const int nch = C >> 3, rpp = 256 / nch;  // 8-channel chunks per row; rows per pass
@@ -456,7 +457,9 @@ __global__ __launch_bounds__(256) void gn_fold_weights_kernel(const f16* __restr
       for (int e = 0; e < 8; ++e) {
         const float wf = (float)w[e];
         o[e] = (f16)(wf * ad[0][cc * 8 + e]);
-        acc += wf * ad[1][cc * 8 + e];
+        // bias term W (beta - mean a): the mean part from the ROUNDED folded weight, so that it cancels the mean the GEMM picks up
+        // through exactly that weight (with rstd up to 1e3 at eps = 1e-6 the rounding of W a would otherwise leak |mean / std| 2^-11)
+        acc += wf * ad[1][cc * 8 + e] - (float)o[e] * ad[2][cc * 8 + e];
       }
       *(f16x8*)(Wb + (size_t)n * ldw + cc * 8) = o;
     }

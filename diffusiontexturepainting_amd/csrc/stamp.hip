@@ -7,6 +7,32 @@
 #include <string.h>
 
 #include "engine.h"
+#include <dlfcn.h>
+
+// roctx ranges around the stages of a stamp (host side, like the reference's NVTX ranges: stable_diffusion_pipeline.py:358-366), so that
+// a rocprofv3 --marker-trace carries the stage names.  Resolved at run time from the ROCm marker library: no link dependency, a no-op
+// when the library is absent.
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      void* h = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL);
+      if (!h) continue;
+      push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (push && pop) return;
+      push = nullptr; pop = nullptr;
+    }
+  }
+};
+const Roctx& roctx() { static Roctx r; return r; }
+struct RoctxRange {
+  explicit RoctxRange(const char* name) { if (roctx().push) roctx().push(name); }
+  ~RoctxRange() { if (roctx().pop) roctx().pop(); }
+};
+}  // namespace
 
 int get_unet_prog(Ctx* c, int N, int dupB, UNetProg** out);
 int get_enc_prog(Ctx* c, int B, VaeEncProg** out);
@@ -439,8 +465,11 @@ int dtp_stamp_slots(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, c
 
   c->last_nodes = 0;
   c->last_evals = E;
+  RoctxRange whole("dtp_stamp");
   HIP_CHECK(hipEventRecord(c->ev[0], s));
   // ---- stage 0: pre-processing + both VAE encodes (one batch-2B pass)
+  {
+  RoctxRange r0("dtp_stamp: pre-processing + vae_encoder x2");
   HIP_CHECK(hipMemcpyAsync(sb->lat, latents, (size_t)B * 4 * HWl * 4, hipMemcpyDeviceToDevice, s));
   if (vae_eps) HIP_CHECK(hipMemcpyAsync(sb->eps, vae_eps, (size_t)2 * B * 4 * HWl * 4, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipMemcpyAsync(c->canvas32, canvas, (size_t)B * 4 * HW * 4, hipMemcpyDeviceToDevice, s));
@@ -459,8 +488,11 @@ int dtp_stamp_slots(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, c
                        c->x32, B, HWl, first_nb);
     return LAUNCH_OK();
   }));
+  }
   HIP_CHECK(hipEventRecord(c->ev[1], s));
   // ---- stage 1: the denoise loop
+  {
+  RoctxRange r1("dtp_stamp: denoise loop (unet)");
   RC(run_stage(c, ((long long)B << 32) | ((long long)steps << 12) | tg_evals | (2LL << 60), s, [&](hipStream_t q) -> int {
     for (int i = 0; i < E; ++i) {
       UNetProg* up = (i < tg_evals) ? u3 : u2;
@@ -476,14 +508,18 @@ int dtp_stamp_slots(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, c
     }
     return LAUNCH_OK();
   }));
+  }
   HIP_CHECK(hipEventRecord(c->ev[2], s));
   // ---- stage 2: latents / 0.18215 -> VAE decode -> clamp (+ composite, u8)
+  {
+  RoctxRange r2("dtp_stamp: vae decode + post-processing");
   RC(run_stage(c, ((long long)B << 32) | (3LL << 60), s, [&](hipStream_t q) -> int {
     RC(launch_post_quant(c, c->x32, 1, 1.0f / VAE_SCALE, dec->in8, B, q));
     return dec->main.run(q, 0);
   }));
   hipLaunchKernelGGL(finish_kernel, dim3(nblk((long long)B * HW)), dim3(256), 0, s, dec->out32, c->canvas32, out, B, HW,
                      st->composite, st->output_u8);
+  }
   c->finite_pending = c->check_finite;
   if (c->check_finite) {
     HIP_CHECK(hipMemsetAsync(c->finite_flag, 0, sizeof(int), s));

@@ -518,7 +518,7 @@ int launch_nhwc_f32_to_nchw(const float* x, float* y, int B, int C, int HW, int 
 
 int get_unet_prog(Ctx* c, int N, int dupB, UNetProg** out) {
   if (!c->dedupe_prefix || dupB >= N) dupB = 0;
-  const int key = N * 64 + dupB;
+  const int key = N * 128 + dupB;  // dupB <= max_batch <= 64: unique
   auto it = c->unet_progs.find(key);
   if (it == c->unet_progs.end()) {
     UNetProg& up = c->unet_progs[key];

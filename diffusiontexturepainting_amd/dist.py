@@ -96,19 +96,27 @@ class PatchGatherer:
 
 
 _gatherers = {}
+_gatherers_group = None
 
 
 def gather_patches(local, n_total, rank, world, dst=0):
     """Gather per-rank patch tensors [b_r, ...] to `dst` in stamp order -> [n_total, ...] on dst, None elsewhere (shards may be
-    ragged).  A convenience wrapper that keeps one PatchGatherer per (shape, dtype, device, layout) alive: the result on `dst`
-    is that gatherer's preallocated buffer and is overwritten by the next call with the same key."""
+    ragged).  A convenience wrapper that keeps one PatchGatherer per (shape, dtype, device, layout) alive and returns a COPY of its
+    buffer (two consecutive results never alias); callers that want the zero-copy path hold a PatchGatherer themselves.  The cache
+    belongs to one process group: it is dropped when the default group changes (destroy_process_group + re-init)."""
+    global _gatherers_group
     if world == 1 and not dist.is_initialized():
         return local
+    group = dist.distributed_c10d._get_default_group()
+    if _gatherers_group is not group:
+        _gatherers.clear()
+        _gatherers_group = group
     key = (int(n_total), tuple(local.shape[1:]), local.dtype, str(local.device), rank, world, dst, dist.get_backend())
     g = _gatherers.get(key)
     if g is None:
         g = _gatherers[key] = PatchGatherer(n_total, local.shape[1:], local.dtype, local.device, rank, world, dst)
-    return g.gather(local)
+    out = g.gather(local)
+    return out.clone() if out is not None else None
 
 
 def scatter_stamps(canvases, n_total, rank, world, src=0, device=None):

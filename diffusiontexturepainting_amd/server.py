@@ -82,6 +82,7 @@ class _Job:
     payload: object                # brush image [3,H,W] f32 / canvas [4,R,R] f32
     reply: callable                # reply(bytes)
     done: threading.Event = field(default_factory=threading.Event)
+    delivered: threading.Event = field(default_factory=threading.Event)  # the reply bytes have been written (see StampQueue._send)
     error: str = None
 
 
@@ -130,32 +131,50 @@ class StampQueue:
             return len(self.clients)
 
     def submit(self, job):
-        if self.stopping:  # nobody would ever take it off the queue
-            self._fail(job, RuntimeError("server is shutting down"))
-            return job
-        self.q.put(job)
+        with self.lock:  # the same lock close() holds while it raises `stopping`: a job is either queued before the drain or refused
+            if not self.stopping:
+                self.q.put(job)
+                return job
+        self._fail(job, RuntimeError("server is shutting down"))  # nobody would ever take it off the queue
         return job
 
     def _send(self, job, data):
+        """Deliver a reply.  `job.done` means "the result exists and has been handed over" (set by the callers, right after this);
+        `job.delivered` is set once the bytes have really been written -- with a `post` hook that happens later, on the IOLoop
+        thread.  (A waiter on the IOLoop thread itself -- on_message(wait=True) in a handler -- must wait on `done`: waiting there
+        for `delivered` would wait for its own thread.)"""
         if self.post is not None:
-            self.post(job.reply, data)
+            def deliver(d, *a, job=job, **kw):
+                try:
+                    job.reply(d, *a, **kw)
+                finally:
+                    job.delivered.set()
+            self.post(deliver, data)
         else:
-            job.reply(data)
+            try:
+                job.reply(data)
+            finally:
+                job.delivered.set()
 
     def close(self):
         """Stop the worker; requests that were still queued are failed (logged, error frame if enabled) instead of being left
         with waiters that never wake up."""
-        self.stopping = True
-        self.q.put(None)
+        with self.lock:
+            self.stopping = True
+            self.q.put(None)
         self.worker.join(timeout=30)
         leftovers, self.front = list(self.front), []
-        while True:
+        while True:  # (after the join: nothing can be enqueued any more, submit() refuses under the lock)
             try:
                 leftovers.append(self.q.get_nowait())
             except queue.Empty:
                 break
         for job in leftovers:
-            if job is not None:
+            if job is None:
+                continue
+            if job.kind == "release":  # internal bookkeeping of detach(): nothing to answer, nothing to log
+                job.done.set()
+            else:
                 self._fail(job, RuntimeError("server is shutting down"))
 
     # ---- worker

@@ -154,6 +154,33 @@ def test_lnlin_activation_stationary_kernel(ops, m, c, n, ranges, geglu, with_bi
     assert (got.float() - other.float()).abs().max().item() <= 2e-2 * max(1.0, other.float().abs().max().item())
 
 
+@pytest.mark.parametrize("m,c,n,ranges,batch", [(12288, 320, 320, 4, 0), (3072, 640, 640, 5, 0), (300, 320, 640, 10, 0), (4096, 320, 320, 2, 3), (1024, 640, 640, 10, 3),
+                                                 (129, 640, 32, 1, 0)])
+def test_lnlin_plain_variant_bias_residual_rowstats_grouped(ops, m, c, n, ranges, batch):
+    """lnlin_kernel without the LayerNorm (tile id 50 on a plain problem): out = A W^T + bias + R with the row statistics of the stored
+    values (one partial per column range), and as a grouped problem (per-sample weights and biases, rows of all samples in one launch)."""
+    nb = max(batch, 1)
+    x = rnd(nb * m, c, seed=195)
+    res = rnd(nb * m, n, seed=196)
+    g = torch.Generator().manual_seed(197)
+    ws = [rnd(n, c, seed=198 + b, scale=c ** -0.5).float() for b in range(nb)]
+    bs = [0.1 * torch.randn(n, generator=g) for _ in range(nb)]
+    ref = torch.cat([F.linear(x[b * m:(b + 1) * m].float(), ws[b], bs[b]) for b in range(nb)]) + res.float()
+    wp = torch.cat([ops.pack_linear(w.cuda()) for w in ws]).contiguous()
+    npad = wp.shape[0] // nb
+    bias = torch.zeros(nb, npad)
+    for b in range(nb):
+        bias[b, :n] = bs[b]
+    got, st = ops.gemm(x.cuda(), wp, n, c, bias=bias.reshape(-1).cuda(), resid=res.cuda(), tile=50, splits=ranges, batch=batch, row_stats=True)
+    close(got, ref, tol=3e-3)
+    assert st.shape[0] == ranges
+    gf = got.float().cpu()
+    want = torch.stack([gf.sum(dim=1), (gf * gf).sum(dim=1)], dim=-1)
+    assert torch.allclose(st.sum(dim=0).cpu(), want, rtol=1e-3, atol=5e-2)
+    other = ops.gemm(x.cuda(), wp, n, c, bias=bias.reshape(-1).cuda(), resid=res.cuda(), tile=2, batch=batch)
+    assert (got.float() - other.float()).abs().max().item() <= 1e-2 * max(1.0, other.float().abs().max().item())
+
+
 @pytest.mark.parametrize("tile", [-1, 2, 5, 8, 33, 34, 39, 41, 46])
 def test_gemm_batched_group_softmax(ops, tile):
     """Grouped GEMM (one weight matrix per batch entry) + LayerNorm fold + softmax over groups of 16 columns (14 valid):

@@ -203,9 +203,11 @@ def test_replies_leave_the_worker_thread_through_the_post_hook():
 
     srv = S.StampServer([FakeModel(delay=0)], error_replies=True, post=S.ioloop_post(loop))
     srv.on_message("c", _brush_msg((9, 9, 9)), write_message, wait=True)
-    srv.on_message("c", _stamp_msg(alpha=255, rgb=255), write_message, wait=True)  # poisoned: an error frame
+    j_err = srv.on_message("c", _stamp_msg(alpha=255, rgb=255), write_message, wait=True)  # poisoned: an error frame
     assert sent == [] and len(loop.items) == 2 and all(t != threading.get_ident() for t, *_ in loop.items)  # produced on the worker ...
+    assert j_err.done.is_set() and not j_err.delivered.is_set()   # done = handed to the loop; delivered = written by the loop
     loop.run_pending()
+    assert j_err.delivered.is_set()
     assert [b for _, b in sent] == [True, True] and set(caller_threads) == {threading.get_ident()}        # ... written on "the loop"
     assert sio.decode_response(sent[0][0])["type"] == sio.RequestType.RETURN_PREVIEW.value and sent[1][0][0] == S.RETURN_ERROR
     srv.close()
