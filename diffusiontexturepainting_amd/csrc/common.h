@@ -168,6 +168,10 @@ struct GemmParams {
   const unsigned char* W8;
   int ldw8;
   float a_scale, w_scale;  // A8 = e4m3(A / a_scale), W8 = e4m3(W / w_scale); powers of two
+  // host-side only (engine.hip make_gemm_op): the calibrated activation scale of this fp8 problem lives at *a_scale_host (read at
+  // enqueue time, i.e. before graph capture); amax_slot1 - 1 = its slot in the context's amax table (0: none)
+  const float* a_scale_host;
+  int amax_slot1;
 };
 
 // K-slices pinned to XCDs.  Block b of a launch runs on XCD b % 8 and every XCD has its own L2: with the split index on grid.z the
@@ -325,4 +329,7 @@ int dtp_launch_conv_halo(const GemmParams& p, int variant, hipStream_t s);
 void dtp_conv_halo_init();
 int dtp_launch_pack_conv_weight_cb(const float* w, f16* out, int Cout, int Cin, int ldw, hipStream_t s);
 int dtp_launch_touch(const void* p, size_t bytes, float* sink, hipStream_t s);
+// max |x| over a [rows][cols] fp16 matrix (row stride ld) -> atomicMax on the float bits at *slot (non-negative floats order like
+// unsigned integers): the amax pass of the fp8 calibration
+int dtp_launch_amax_f16(const f16* x, long long rows, int cols, int ld, unsigned int* slot, hipStream_t s);
 int dtp_launch_lora_merge(float* w, const float* up, const float* down, int N, int K, int rank, float scale, hipStream_t s);

@@ -266,6 +266,30 @@ int dtp_launch_lora_merge(float* w, const float* up, const float* down, int N, i
   LAUNCH_RET();
 }
 
+__global__ void amax_f16_kernel(const f16* __restrict__ x, long long rows, int cols, int ld, unsigned int* __restrict__ slot) {
+  const int c8 = cols >> 3;  // cols % 8 == 0
+  const long long total = rows * c8;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / c8;
+    const f16x8 v = *(const f16x8*)(x + r * ld + (i - r * c8) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v[e]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));
+}
+
+int dtp_launch_amax_f16(const f16* x, long long rows, int cols, int ld, unsigned int* slot, hipStream_t s) {
+  if ((cols & 7) || (ld & 7)) { dtp_set_error("amax: cols %d / ld %d must be multiples of 8", cols, ld); return DTP_ERR_ARG; }
+  const long long total = rows * (cols >> 3);
+  int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(amax_f16_kernel, dim3(blocks), dim3(256), 0, s, x, rows, cols, ld, slot);
+  return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+}
+
 int dtp_launch_touch(const void* p, size_t bytes, float* sink, hipStream_t s) {
   const long long n16 = (long long)(bytes / 16);
   if (n16 <= 0) return DTP_OK;

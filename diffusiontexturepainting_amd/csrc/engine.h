@@ -1,6 +1,7 @@
 // Host-side engine of libdtp: weight staging/packing, static activation planning and the
 // launch programs of the three networks.  One Ctx = one GPU; not thread-safe (include/dtp.h).
 #pragma once
+#include <deque>
 #include <functional>
 #include <map>
 #include <string>
@@ -140,8 +141,23 @@ struct Pool {
   size_t total = 0;
 };
 
+// fp8 calibration (configs[4]): every fp8 problem whose activation operand is not LayerNorm'd gets its scale from the absolute maximum
+// its operand reached in one evaluation of the program (Ctx::calibrating: the ops also launch dtp_launch_amax_f16 on their inputs)
+struct Fp8Cal {
+  int kind = 0;            // 0: Linear / 1x1 conv (slot0 = A [| A2]), 1: self-attention (slot0 .. slot0 + 2 = Q, K, V)
+  int slot0 = 0;
+  float* s0 = nullptr;     // Linear: a_scale; attention: q_scale
+  float* s1 = nullptr;     // attention: v_scale
+  float softmax_scale = 1.f;
+};
+constexpr int DTP_FP8_SLOTS = 2048;
+constexpr float DTP_FP8_LN_A_SCALE = 0.125f;  // LayerNorm'd operands: |x| <= sqrt(K - 1) < 36 -> x * 8 < 448 never clips, three more octaves above the subnormals
+constexpr float DTP_FP8_MARGIN = 2.0f;        // head-room over the calibration evaluation's absolute maximum
+
 struct UNetProg {
   int N = 0;          // UNet batch (3B or 2B)
+  size_t cal_begin = 0, cal_end = 0;  // this program's records in Ctx::fp8_cals
+  bool fp8_calibrated = false;
   Prog kv, main;
   f16* in16 = nullptr;     // [N][h][w][16] input (latent 0-3, mask 4, masked latents 5-8, zero 9-15)
   f16* ctx16 = nullptr;    // [N][14][768]
@@ -250,6 +266,11 @@ struct Ctx {
   bool pack_ws = false;           // load_conv also builds the fragment-order packing (set while the UNet's weights load; $DTP_NO_WS=1: never)
   bool fp8_linear = false;        // UNet transformer Linears / 1x1 convs on the fp8 MX MFMA (configs[4]); fixed once a UNet program exists
   bool fp8_attention = false;     // UNet self-attention on the fp8 MX MFMA (BASELINE configs[4]); fixed once a UNet program exists
+  std::deque<float> fp8_scales;   // host copies of the calibrated scales (stable addresses: the ops read them at enqueue time)
+  std::deque<Fp8Cal> fp8_cals;
+  unsigned int* fp8_amax = nullptr;  // device: DTP_FP8_SLOTS float bit patterns
+  int fp8_nslots = 0;
+  bool calibrating = false;
   bool finite_pending = false;    // the last stamp ran the check; dtp_last_stamp_finite reads the flag
   std::map<long long, StampGraph> graphs;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -336,7 +357,10 @@ int build_vae_dec_prog(Ctx* c, int B, VaeDecProg& p);
 int load_unet_weights(Ctx* c);
 int load_vae_weights(Ctx* c);
 int ensure_ws(Ctx* c);
-int ensure_w8(Ctx* c, ConvW& w);  // build the e4m3 copy of a Linear's packed weights (once)
+int ensure_w8(Ctx* c, ConvW& w);
+// fp8 calibration: new scale / amax-slot pair for a Linear (returns the scale's address, sets *slot1), and the pass itself
+float* fp8_new_linear_scale(Ctx* c, int* slot1);
+int fp8_calibrate(Ctx* c, UNetProg* up, hipStream_t s, int step);  // build the e4m3 copy of a Linear's packed weights (once)
 void tune_cache_load(Ctx* c);
 void tune_cache_save(Ctx* c);
 int ensure_temb(Ctx* c, const std::vector<float>& timesteps);  // fills temb_table rows 0..n-1

@@ -770,10 +770,57 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
   return DTP_OK;
 }
 
+float* fp8_new_linear_scale(Ctx* c, int* slot1) {
+  if (c->fp8_nslots + 1 > DTP_FP8_SLOTS) { *slot1 = 0; return nullptr; }
+  c->fp8_scales.push_back(1.0f);
+  Fp8Cal r;
+  r.kind = 0; r.slot0 = c->fp8_nslots; r.s0 = &c->fp8_scales.back();
+  c->fp8_cals.push_back(r);
+  *slot1 = ++c->fp8_nslots;
+  return r.s0;
+}
+
+// One evaluation of the program with every fp8 op also measuring the absolute maximum of its operands, then power-of-two scales:
+// amax * margin / scale <= 448 (the largest e4m3 value), as large a mantissa use as that allows.  Synchronises the stream once.
+int fp8_calibrate(Ctx* c, UNetProg* up, hipStream_t s, int step) {
+  if (up->fp8_calibrated || up->cal_begin == up->cal_end) { up->fp8_calibrated = true; return DTP_OK; }
+  if (!c->fp8_amax) { void* p; RC(ctx_persistent(c, DTP_FP8_SLOTS * sizeof(unsigned int), &p, true)); c->fp8_amax = (unsigned int*)p; }
+  HIP_CHECK(hipMemsetAsync(c->fp8_amax, 0, DTP_FP8_SLOTS * sizeof(unsigned int), s));
+  c->calibrating = true;
+  const int rc = up->main.run(s, step);
+  c->calibrating = false;
+  RC(rc);
+  std::vector<float> amax(DTP_FP8_SLOTS);
+  HIP_CHECK(hipMemcpyAsync(amax.data(), c->fp8_amax, DTP_FP8_SLOTS * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  auto pow2_for = [](float a) { return a > 0.f ? exp2f(ceilf(log2f(a * DTP_FP8_MARGIN / 448.0f))) : 1.0f; };
+  for (size_t i = up->cal_begin; i < up->cal_end; ++i) {
+    Fp8Cal& r = c->fp8_cals[i];
+    if (r.kind == 0) {
+      *r.s0 = pow2_for(amax[r.slot0]);
+    } else {
+      // Q' = Q * (softmax_scale * log2 e * q_scale), K' = K / q_scale: balance the two absolute maxima (their product is fixed)
+      const float aq = amax[r.slot0] * r.softmax_scale * 1.4426950408889634f, ak = amax[r.slot0 + 1], av = amax[r.slot0 + 2];
+      *r.s0 = (aq > 0.f && ak > 0.f) ? exp2f(roundf(0.5f * log2f(ak / aq))) : 1.0f;
+      *r.s1 = pow2_for(av);
+    }
+  }
+  up->fp8_calibrated = true;
+  return DTP_OK;
+}
+
 static Op make_gemm_op(Ctx* c, GemmParams p, int tile, int bias_step_off) {
   return [=](hipStream_t s, int step) -> int {
     GemmParams q = p;
     q.part = c->ws;
+    if (p.a_scale_host) {  // fp8 with a calibrated activation scale
+      if (c->calibrating && p.amax_slot1 > 0) {
+        const int ka = p.A2 ? p.K - p.Cin2 : p.K;
+        RC(dtp_launch_amax_f16(p.A, p.M, ka, p.lda, c->fp8_amax + p.amax_slot1 - 1, s));
+        if (p.A2) RC(dtp_launch_amax_f16(p.A2, p.M, p.Cin2, p.lda2, c->fp8_amax + p.amax_slot1 - 1, s));
+      }
+      q.a_scale = *p.a_scale_host;
+    }
     if (bias_step_off >= 0) q.bias = c->temb_table + (size_t)step * c->unet.temb_total + bias_step_off;
     if (tile == DTP_TILE_LNLIN) return dtp_launch_lnlin(q, q.col_ranges, s);
     if (dtp_is_ws_tile(tile)) return dtp_launch_conv_ws(q, tile - DTP_TILE_WS0, s);
@@ -940,8 +987,13 @@ int Builder::linear(const T& x, const ConvW& w, const T* resid, int flags, T& y,
   }
   if (fp8 && w.w8) {
     GemmParams q = p;
-    q.W8 = w.w8; q.ldw8 = w.ldw8; q.w_scale = w.w8_scale; q.a_scale = 1.0f; q.splits = 1;
-    if (dtp_gemm_fp8_supported(q)) p = q;  // otherwise the fp16 kernel takes it
+    q.W8 = w.w8; q.ldw8 = w.ldw8; q.w_scale = w.w8_scale; q.splits = 1;
+    // activation scale: a LayerNorm'd operand is bounded (fixed scale); anything else is calibrated (fp8_calibrate)
+    q.a_scale = (p.flags & GF_LNFOLD) ? DTP_FP8_LN_A_SCALE : DTP_FP8_LN_A_SCALE * 8.0f;
+    if (dtp_gemm_fp8_supported(q)) {
+      if (!(p.flags & GF_LNFOLD) && (q.K & 7) == 0) q.a_scale_host = fp8_new_linear_scale(c, &q.amax_slot1);
+      p = q;  // otherwise the fp16 kernel takes it
+    }
   }
   return push_gemm(c, prog, p, -1, (double)w.K, (emit && emit->buf) ? emit : nullptr);
 }
@@ -956,8 +1008,31 @@ int Builder::attention(const T& q, const T& k, const T& v, int heads, int Sq, in
   a.qbs = (long long)Sq * q.ld; a.kbs = (long long)Skv * k.ld; a.vbs = (long long)Skv * v.ld; a.obs = (long long)Sq * o.ld;
   a.scale = 1.0f / sqrtf((float)a.D);
   const bool fp8 = c->fp8_attention && (a.D % 64) != 0 && a.D <= 184 && Skv >= 64;  // the brush encoder's tiny attentions stay f16
+  const float *qs = nullptr, *vs = nullptr;
+  int slot0 = -1;
+  if (fp8 && c->fp8_nslots + 3 <= DTP_FP8_SLOTS && (q.C & 7) == 0) {  // calibrated Q / K and V scales (fp8_calibrate)
+    Ctx* cc0 = c;
+    cc0->fp8_scales.push_back(1.0f); float* s0 = &cc0->fp8_scales.back();
+    cc0->fp8_scales.push_back(1.0f); float* s1 = &cc0->fp8_scales.back();
+    Fp8Cal r;
+    r.kind = 1; r.slot0 = cc0->fp8_nslots; r.s0 = s0; r.s1 = s1; r.softmax_scale = a.scale;
+    cc0->fp8_cals.push_back(r);
+    slot0 = cc0->fp8_nslots;
+    cc0->fp8_nslots += 3;
+    qs = s0; vs = s1;
+  }
+  Ctx* cc = c;
+  const T qq = q, kk = k, vv = v;
   push(PK_ATTN, 4.0 * Bn * heads * (double)Sq * Skv * a.D, 2.0 * Bn * q.C * (2.0 * Sq + 2.0 * Skv),
-       [=](hipStream_t s, int) { return fp8 ? dtp_launch_attention_fp8(a, 1.0f, 1.0f, s) : dtp_launch_attention(a, s); },
+       [=](hipStream_t s, int) {
+         if (!fp8) return dtp_launch_attention(a, s);
+         if (cc->calibrating && slot0 >= 0) {
+           RC(dtp_launch_amax_f16(qq.p, (long long)Bn * Sq, qq.C, qq.ld, cc->fp8_amax + slot0, s));
+           RC(dtp_launch_amax_f16(kk.p, (long long)Bn * Skv, kk.C, kk.ld, cc->fp8_amax + slot0 + 1, s));
+           RC(dtp_launch_amax_f16(vv.p, (long long)Bn * Skv, vv.C, vv.ld, cc->fp8_amax + slot0 + 2, s));
+         }
+         return dtp_launch_attention_fp8(a, qs ? *qs : 1.0f, vs ? *vs : 1.0f, s);
+       },
        "attn B=" + std::to_string(Bn) + " Sq=" + std::to_string(Sq) + " Skv=" + std::to_string(Skv) + " D=" + std::to_string(a.D));
   return DTP_OK;
 }

@@ -490,6 +490,16 @@ int dtp_stamp_slots(dtp_ctx* ctx, const float* canvas, const dtp_settings* st, c
   }));
   }
   HIP_CHECK(hipEventRecord(c->ev[1], s));
+  // fp8 (configs[4]): the first stamp of a program measures its activation ranges once, before the loop is captured
+  if ((c->fp8_linear || c->fp8_attention)) {
+    if (u3 && !u3->fp8_calibrated) RC(fp8_calibrate(c, u3, s, 0));
+    if (u2 && !u2->fp8_calibrated) {
+      if (tg_evals > 0)  // (u2 is not the first program:) its input is normally assembled where the loop switches programs: do it now, from the initial latents
+        hipLaunchKernelGGL(assemble_kernel, dim3(nblk((long long)B * HWl)), dim3(256), 0, s, (const float*)nullptr, sb->masks, sb->ml, u2->in16,
+                           c->x32, B, HWl, 2);
+      RC(fp8_calibrate(c, u2, s, 0));
+    }
+  }
   // ---- stage 1: the denoise loop
   {
   RoctxRange r1("dtp_stamp: denoise loop (unet)");

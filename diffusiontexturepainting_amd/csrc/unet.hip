@@ -315,8 +315,11 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
     g.flags = GF_BIAS | GF_RESID;
     if (b.fp8 && wm.w8) {
       GemmParams q = g;
-      q.W8 = wm.w8; q.ldw8 = wm.ldw8; q.w_scale = wm.w8_scale; q.a_scale = 1.0f; q.splits = 1;
-      if (dtp_gemm_fp8_supported(q)) g = q;
+      q.W8 = wm.w8; q.ldw8 = wm.ldw8; q.w_scale = wm.w8_scale; q.a_scale = DTP_FP8_LN_A_SCALE * 8.0f; q.splits = 1;
+      if (dtp_gemm_fp8_supported(q)) {  // [GEGLU output | residual stream]: un-normalised operands, calibrated scale (fp8_calibrate)
+        q.a_scale_host = fp8_new_linear_scale(b.c, &q.amax_slot1);
+        g = q;
+      }
     }
     RC(push_gemm(b.c, b.prog, g, -1, (double)wm.K, nullptr));
     b.release(f); b.release(y3);
@@ -396,6 +399,7 @@ int build_unet_prog(Ctx* c, int N, int dupB, UNetProg& up) {
     // the quantise kernels run on the null stream, the program on the caller's (non-blocking) stream: order them once, here
     HIP_CHECK(hipDeviceSynchronize());
   }
+  up.cal_begin = c->fp8_cals.size();
   Builder b{c, &up.main};
   b.fp8 = c->fp8_linear;
   T x0;
@@ -495,6 +499,7 @@ int build_unet_prog(Ctx* c, int N, int dupB, UNetProg& up) {
   b.release(x);
   RC(b.conv3(t, u.conv_out, 1, 1, false, h, h, nullptr, -1, o, GF_OUT_F32, up.out32, 4));
   b.release(t);
+  up.cal_end = c->fp8_cals.size();
   tune_cache_save(c);
   return ensure_ws(c);
 }
@@ -548,6 +553,7 @@ extern "C" int dtp_unet(dtp_ctx* ctx, const float* sample, float timestep, const
   up->kv_ver = 0;  // K/V now belong to the caller's conditioning
   up->kv_slots.clear();
   RC(up->kv.run(s, 0));
+  RC(fp8_calibrate(c, up, s, 0));  // (first call of an fp8 context only)
   RC(up->main.run(s, 0));
   return launch_nhwc_f32_to_nchw(up->out32, out, N, 4, hw, 4, s);
 }

@@ -3,6 +3,8 @@
 // (encode(x).latent_dist.sample()), I/O contracts :1253-1284, :1343-1377; topology SURVEY.md A.2.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "engine.h"
 
 int launch_nhwc_f32_to_nchw(const float* x, float* y, int B, int C, int HW, int ldx, hipStream_t s);
@@ -28,6 +30,11 @@ static int load_attn_v(Ctx* c, const std::string& p, VaeAttnW& w) {
 }
 
 int load_vae_weights(Ctx* c) {
+  struct WsScope {  // the VAE's 3x3 convs (64 ... 512 pixel maps, 128 ... 512 channels) also get the fragment-order packing (conv_ws.hip)
+    Ctx* c;
+    explicit WsScope(Ctx* cc) : c(cc) { const char* e = getenv("DTP_NO_WS"); const char* v = getenv("DTP_NO_WS_VAE"); c->pack_ws = !(e && e[0] && e[0] != '0') && !(v && v[0] && v[0] != '0'); }
+    ~WsScope() { c->pack_ws = false; }
+  } ws_scope(c);
   VaeW& v = c->vae;
   const std::string P = "vae.";
   RC(load_conv(c, P + "encoder.conv_in", v.enc_in, 8));

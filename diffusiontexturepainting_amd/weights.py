@@ -244,6 +244,30 @@ def synthetic_unet(seed=0):
     return synthetic_state_dict(unet_spec(), seed)
 
 
+def synthetic_unet_trained_like(seed=0, rank=8, outlier=50.0):
+    """A seeded UNet whose transformer Linears look more like a TRAINED network's than i.i.d. noise does (no checkpoint is reachable
+    here): every attention / feed-forward weight is low-rank (rank 8) plus small noise -- dot products add up coherently, as
+    they do with trained weights -- and a few channels are outliers: three rows of the value half of every GEGLU projection
+    (ff.net.0.proj) and of every attn1.to_v are scaled by `outlier`, which puts x50 channels into the inputs of ff.net.2 and
+    attn1.to_out, the two un-normalised fp8 operands (tests: fp8 with calibrated activation scales, fp16 with outlier statistics)."""
+    sd = synthetic_unet(seed)
+    for k in sorted(sd):
+        w = sd[k]
+        if ".transformer_blocks." not in k or not k.endswith(".weight") or w.dim() != 2 or ".norm" in k:
+            continue
+        g = torch.Generator().manual_seed(_seed_for(k + "/lowrank", seed))
+        n, kk = w.shape
+        std = w.std()
+        low = (torch.randn(n, rank, generator=g) @ torch.randn(rank, kk, generator=g)) / np.sqrt(rank)
+        w = 0.95 * std * low + 0.3 * w
+        if k.endswith("ff.net.0.proj.weight"):
+            w[[1, 17, 33]] *= outlier              # rows of the value half ([0, inner)): outlier channels of the GEGLU output
+        if k.endswith("attn1.to_v.weight"):
+            w[[2, 18, 34]] *= outlier
+        sd[k] = w
+    return sd
+
+
 def synthetic_lora(seed=0):
     return synthetic_state_dict(lora_spec(), seed)
 

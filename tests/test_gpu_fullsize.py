@@ -115,15 +115,15 @@ def test_256_10steps_matches_cpu_oracle(weights):
     assert err <= 1e-2 and m.stamp_info()["unet_evals"] == 9
 
 
-FP8_ATTN_PIXEL_TOL = 3e-2  # BASELINE configs[4], attention only: fp8 (e4m3) operands cost more than the 1e-2 of the fp16 path
-FP8_FULL_PIXEL_TOL = 6e-2  # ... with the transformer Linears / 1x1 convs in fp8 as well.  Seeded RANDOM weights are the worst case for
-# a 3-mantissa-bit contraction: the terms of every dot product are incoherent, so each GEMM output carries ~5 % relative noise
-# (with trained weights the sums are coherent and the relative error is a fraction of that); measured 3.9e-2.
+FP8_ATTN_PIXEL_TOL = 1e-2  # BASELINE configs[4]: north_star's gate, the same as the fp16 path's -- since round 4 the fp8 operands carry
+FP8_FULL_PIXEL_TOL = 1e-2  # calibrated power-of-two scales (LayerNorm'd operands x 8, the others from an amax pass of the first evaluation):
+# measured 2.6e-3 (attention) / 3.1e-3 (attention + Linears) against 2.2e-3 in fp16; with unit scales it was 3.9e-2 (most of a
+# LayerNorm'd operand sat in e4m3's subnormal range below 2^-6)
 
 
 def test_config4_256_8steps_fp8(weights):
     """configs[4]: 256 x 256, 8 DDIM steps against the fp32 CPU oracle in three precisions: fp16 (gate 1e-2), fp8 self-attention
-    (stated tolerance 3e-2), fp8 self-attention + transformer Linears / 1x1 convs (stated tolerance 6e-2, see above)."""
+    and fp8 self-attention + transformer Linears / 1x1 convs: all three inside north_star's 1e-2."""
     from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
     from oracle import pipeline
     canvas, brush, cond, uncond, lat, eps = _inputs(1, 256, 400)
@@ -140,6 +140,42 @@ def test_config4_256_8steps_fp8(weights):
         assert torch.isfinite(got).all() and m.stamp_info()["unet_evals"] == 7
     assert errs[False] <= 1e-2 and errs["attention"] <= FP8_ATTN_PIXEL_TOL and errs["full"] <= FP8_FULL_PIXEL_TOL
     assert len({errs[False], errs["attention"], errs["full"]}) == 3  # the options really switched the kernels
+
+FP8_TRAINED_LIKE_TOL = 1e-2  # fp8 attention + Linears with CALIBRATED activation scales on the trained-like weight set (measured 5.4e-3)
+
+
+def test_trained_like_weights_256_8steps_fp16_and_calibrated_fp8():
+    """Statistics a trained checkpoint would show and i.i.d. weights do not (weights.synthetic_unet_trained_like: low-rank coherent
+    transformer Linears, x50 outlier channels in the GEGLU output and in the attention values): the fp16 path must hold the 1e-2 gate
+    of north_star with them (fp16 activation storage, LayerNorm folded from E[x^2] - mean^2, 7 evaluations), and the fp8 path --
+    whose un-normalised operands (attn1.to_out and ff.net.2 inputs, Q / K / V) get per-layer power-of-two scales from an amax pass of
+    the first evaluation -- must stay finite and inside its stated tolerance WITH the outliers (at unit scale a x50 channel
+    saturates e4m3 at +-448).  Both errors are printed next to the random-weight figures of test_config4_256_8steps_fp8."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffusiontexturepainting_amd import weights as W
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    from oracle import nets, pipeline
+    sd = dict(unet=W.synthetic_unet_trained_like(7), lora=W.synthetic_lora(7), vae=W.synthetic_vae(7))
+    ow = dict(unet=nets.merge_lora(sd["unet"], sd["lora"]), vae=sd["vae"])
+    canvas, brush, cond, uncond, lat, eps = _inputs(1, 256, 450)
+    st = dict(steps=8, context_pad=150, tg_steps=4, cfg_weight=2.0, tg_weight=1.0)  # tg cut-off mid-loop: both programs calibrate
+    ref = pipeline.generate_raw(ow, brush, cond, uncond, canvas, lat, eps, **st)
+    errs = {}
+    for fp8 in (False, True):
+        m = MI355ConditionalInpainter(256, device=0, weights=sd, max_batch=1, fp8_attention=fp8, fp8_linear=fp8)
+        m.set_option("check_finite", 1)
+        m.set_conditioning(cond, uncond, brush)
+        got = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
+        torch.cuda.synchronize()
+        errs[fp8] = (got.cpu() - ref).abs().max().item()
+        print(f"trained-like weights, 256^2 / 8 steps, fp8={fp8}: max abs pixel error {errs[fp8]:.2e}")
+        assert torch.isfinite(got).all() and m.last_stamp_finite() and m.stamp_info()["unet_evals"] == 7
+        again = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)  # the calibrated scales are fixed: replay is bit-identical
+        assert torch.equal(got, again)
+    assert errs[False] <= 1e-2
+    assert errs[True] <= FP8_TRAINED_LIKE_TOL and errs[True] != errs[False]
+
 
 @pytest.mark.skipif(bool(os.environ.get("DTP_SKIP_FULLSIZE")), reason="DTP_SKIP_FULLSIZE=1: skip the ~4 minutes of host time (builder iterations only)")
 def test_config1_512_20steps_matches_cpu_oracle(model512, weights):
@@ -207,6 +243,6 @@ def test_groupnorm_applied_on_the_conv_input_patch(weights):
         del m
     ref = pipeline.generate_raw(weights[1], brush, cond, uncond, canvas, lat, eps, **st)
     assert (outs[0][0] - ref).abs().max().item() <= 1e-2 and (outs[1][0] - ref).abs().max().item() <= 1e-2
-    assert outs[0][1] < outs[1][1]                       # fewer launches: the apply passes are gone ...
-    assert not torch.equal(outs[0][0], outs[1][0])       # ... and the option really switched the kernels
+    # (round 4: the default path gets its GroupNorm statistics from the conv epilogues and has no more launches than this option)
+    assert not torch.equal(outs[0][0], outs[1][0])       # the option really switched the kernels
     assert (outs[0][0] - outs[1][0]).abs().max().item() <= 5e-3

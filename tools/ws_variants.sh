@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 OBJ=diffusiontexturepainting_amd/csrc/build
 mkdir -p tools/ab
-for v in NO_MFMA NO_LDSREAD NO_WLOAD NO_DMA; do
+for v in ${WS_VARIANTS:-NO_MFMA NO_LDSREAD NO_WLOAD NO_DMA}; do
   lc=$(echo $v | tr 'A-Z' 'a-z' | tr -d '_')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DDTP_WS_$v -c diffusiontexturepainting_amd/csrc/conv_ws.hip -o /tmp/conv_ws_$lc.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ab/libdtp_ws_$lc.so $(ls $OBJ/*.o | grep -v conv_ws.o) /tmp/conv_ws_$lc.o
