@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILE = "r03_pmc_unet_traffic.json"  # tools/pmc_unet.sh, committed with the sha1 of the kernel sources it was collected on
+PMC_TRAFFIC_FILE = "r04_pmc_unet_traffic.json"  # tools/pmc_unet.sh, committed with the sha1 of the kernel sources it was collected on
 
 
 def cpu_baseline(res, ddim_steps, weights, budget_note):

@@ -1,0 +1,33 @@
+# Round-4 profile refresh, one gpurun call (run from the repo root on the GPU box).  Order matters: the PMC traffic summary is
+# collected first and copied to profiles/ so that the bench lines of the same call can carry it (bench.py reports it only when its
+# kernel-source hash matches the running build).  Everything lands in gpurun_out/r04_*; copy what should be judged into profiles/.
+export DTP_ROUND=r04
+bash tools/pmc_unet.sh
+cp gpurun_out/r04_pmc_unet_traffic.json profiles/r04_pmc_unet_traffic.json
+export DTP_TUNE_CACHE=/tmp/tc.txt
+timeout 1200 python bench.py > gpurun_out/r04_b1.log 2>gpurun_out/r04_b1.err
+timeout 600 python bench.py --batch 8 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/r04_b8.log 2>gpurun_out/r04_b8.err
+timeout 600 python bench.py --res 256 --no-cpu-baseline --no-extras > gpurun_out/r04_256.log 2>gpurun_out/r04_256.err
+DTP_BENCH_BACKEND=gloo DTP_BENCH_SAME_DEVICE=1 timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-profile > gpurun_out/r04_gpus2_same_device.log 2>gpurun_out/r04_gpus2_same_device.err
+DTP_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-profile > gpurun_out/r04_rccl_one_rank.log 2>gpurun_out/r04_rccl_one_rank.err
+timeout 600 python bench.py --cpu-config0 > gpurun_out/r04_cpu_config0.json 2>gpurun_out/r04_cpu_config0.err
+DTP_FULLSIZE_JSON=gpurun_out/r04_fullsize_parity.json timeout 900 python -m pytest tests/test_gpu_fullsize.py -q -x -k test_config1_512_20steps_matches_cpu_oracle > gpurun_out/r04_fullsize_parity.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r04 -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-extras > /root/repo/gpurun_out/r04_prof.log 2>&1
+find /tmp/prof -name "*kernel_stats*" -exec cp {} /root/repo/gpurun_out/r04_kernel_stats.csv \;
+rm -rf /tmp/prof8
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof8 -o r04 -- python /root/repo/bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras > /root/repo/gpurun_out/r04_prof_b8.log 2>&1
+find /tmp/prof8 -name "*kernel_stats*" -exec cp {} /root/repo/gpurun_out/r04_kernel_stats_b8.csv \;
+cp /tmp/tc.txt /root/repo/gpurun_out/r04_tune_cache.txt
+cd /root/repo
+tools/micro/exp_rate > gpurun_out/r04_exp_rate.log 2>&1
+# roctx stage ranges (stamp.hip): the marker trace of a short run carries the stage names
+cd /tmp && rm -rf /tmp/profm
+timeout 600 rocprofv3 --marker-trace --stats --output-format csv -d /tmp/profm -o r04 -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras > /root/repo/gpurun_out/r04_prof_marker.log 2>&1
+find /tmp/profm -name "*marker*stats*" -exec cp {} /root/repo/gpurun_out/r04_marker_stats.csv \;
+find /tmp/profm -name "*marker_api_trace.csv" -exec sh -c 'head -40 "$1" > /root/repo/gpurun_out/r04_marker_trace_head.csv' _ {} \;
+cd /root/repo
+timeout 600 python tools/diag_ws.py --cold --noreduce > gpurun_out/r04_diag_ws_cold.log 2>&1
+timeout 600 python tools/diag_ws.py --big --noreduce > gpurun_out/r04_diag_ws_big.log 2>&1
+timeout 600 python tools/diag_ws.py --tail --noreduce > gpurun_out/r04_diag_ws_tail.log 2>&1
