@@ -33,7 +33,8 @@ PROF_KINDS = [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 
     [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, {2 + i // 4}, 2>" for i in range(8)] + \
     [f"gemm_kernel<{_SHAPES[i & 3][0]}, {_SHAPES[i & 3][1]}, 3, 1, {(4, 8)[i // 4]}>" for i in range(8)] + \
     ["xattn_kernel (cross-attention GEMM pair)", "conv_halo_kernel<8, 8, 64, 3 images>", "conv_halo_kernel<8, 8, 128, 3 images>",
-     "lnlin_kernel (activation-stationary LayerNorm-folded Linear / GEGLU)", "convws_kernel<8, 8, 3 images>", "convws_kernel<16, 16>", "convws_kernel<8, 16, 2 n-tiles>", "convws_kernel<8, 16, 2 n-tiles, 2 workgroups per CU>"]
+     "lnlin_kernel (activation-stationary LayerNorm-folded Linear / GEGLU)", "convws_kernel<8, 8, 3 images>", "convws_kernel<16, 16>", "convws_kernel<8, 16, 2 n-tiles>", "convws_kernel<8, 16, 2 n-tiles, 2 workgroups per CU>",
+     "gemmws_kernel (weight-streaming dense GEMM)"]
 
 
 class GemmDesc(C.Structure):
@@ -92,6 +93,8 @@ SYMBOLS = {
     "dtp_op_groupnorm_apply": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "dtp_op_pack_conv_ws": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "dtp_op_pack_conv_ws_elems": (C.c_longlong, [_i, _i, _i]),
+    "dtp_op_pack_linear_ws": (_i, [_vp, _i, _vp, _i, _i, _vp]),
+    "dtp_op_pack_linear_ws_elems": (C.c_longlong, [_i, _i]),
     "dtp_op_groupnorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "dtp_op_measure_peaks": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dtp_op_reduce_groupnorm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

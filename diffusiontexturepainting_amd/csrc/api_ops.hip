@@ -64,7 +64,7 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
   int rc = ops_init();
   if (rc) return rc;
   static bool halo_init = false;
-  if (!halo_init) { dtp_conv_halo_init(); dtp_gemm_wide_init(); dtp_lnlin_init(); dtp_conv_ws_init(); halo_init = true; }
+  if (!halo_init) { dtp_conv_halo_init(); dtp_gemm_wide_init(); dtp_lnlin_init(); dtp_conv_ws_init(); dtp_gemm_ws_init(); halo_init = true; }
   GemmParams p = {};
   p.A = (const f16*)d->A; p.W = (const f16*)d->W; p.C = d->C; p.bias = d->bias; p.R = (const f16*)d->R;
   p.zero = g_ops.zero;
@@ -99,7 +99,7 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
     p.W = (const f16*)d->Wcb;
     dtp_split_k(p.nkb, tile, d->splits >= 1 ? d->splits : 1, &p.kb_per_split, &p.splits);
   }
-  if (dtp_is_ws_tile(tile)) dtp_split_k(p.nkb, tile, d->splits >= 1 ? d->splits : 1, &p.kb_per_split, &p.splits);
+  if (dtp_is_ws_tile(tile) || tile == DTP_TILE_GEMMWS) dtp_split_k(p.nkb, tile, d->splits >= 1 ? d->splits : 1, &p.kb_per_split, &p.splits);
   rc = ops_ws(dtp_gemm_workspace_bytes(p));
   if (rc) return rc;
   p.part = g_ops.ws;
@@ -109,7 +109,9 @@ int dtp_op_gemm(dtp_gemm_desc* d, dtp_stream s) {
     (void)dtp_gemm_tile_dims(tile, &bm, &bn, &ns);
     d->st_parts_out = p.splits > 1 ? 1 : (p.N + bn - 1) / bn;
     if (tile == DTP_TILE_LNLIN) d->st_parts_out = d->splits >= 1 ? d->splits : 4;  // one partial per column range
+    if (tile == DTP_TILE_GEMMWS) d->st_parts_out = p.splits > 1 ? 1 : (p.N + 63) / 64;
   }
+  if (tile == DTP_TILE_GEMMWS) return dtp_launch_gemm_ws(p, (hipStream_t)s);
   if (tile == DTP_TILE_LNLIN) return dtp_launch_lnlin(p, d->splits >= 1 ? d->splits : 4, (hipStream_t)s);
   if (dtp_is_halo_tile(tile)) return dtp_launch_conv_halo(p, dtp_halo_variant(tile), (hipStream_t)s);
   return dtp_launch_gemm(p, tile, (hipStream_t)s);
@@ -160,6 +162,10 @@ int dtp_op_pack_conv_cb(const float* w, void* out, int Cout, int Cin, int ldw, d
 int dtp_op_pack_conv_ws(const float* w, const float* w1, void* out, int Cout, int Cin, int Cin2, dtp_stream s) {
   return dtp_launch_pack_conv_ws(w, w1, (f16*)out, Cout, Cin, Cin2, (hipStream_t)s);
 }
+int dtp_op_pack_linear_ws(const void* w, int ldw, void* out, int N, int K, dtp_stream s) {
+  return dtp_launch_pack_linear_ws((const f16*)w, ldw, (f16*)out, N, K, (hipStream_t)s);
+}
+long long dtp_op_pack_linear_ws_elems(int N, int K) { return (long long)dtp_gemm_ws_packed_elems(N, K); }
 long long dtp_op_pack_conv_ws_elems(int Cout, int Cin, int Cin2) { return (long long)dtp_conv_ws_packed_elems(Cout, Cin, Cin2); }
 
 int dtp_op_groupnorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,

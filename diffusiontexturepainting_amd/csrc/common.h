@@ -131,7 +131,8 @@ struct GemmParams {
   const f16* A;      // activations: dense [M][lda] or NHWC image for CONV3
   const f16* W;      // weights [N_pad][ldw], K contiguous, zero padded to k-block multiples
   const f16* Wcb;    // same 3x3 weights packed channel-block-major (k' = (cb*9+tap)*64 + c) for conv_halo_kernel; may be null
-  const f16* Wfr;    // same 3x3 weights (+ the fused shortcut's 1x1 weights behind them) in MFMA fragment order for convws_kernel (conv_ws.hip); may be null
+  const f16* Wfr;    // same 3x3 weights (+ the fused shortcut's 1x1 weights behind them) in MFMA fragment order for convws_kernel (conv_ws.hip), or the
+                     // dense weights in fragment order for gemmws_kernel (gemm_ws.hip); may be null
   void* C;           // fp16 [M][ldc] (or fp32 with GF_OUT_F32)
   float* part;       // split-K partial slabs [splits][M][N] fp32 (when splits > 1)
   const float* bias; // fp32
@@ -300,14 +301,15 @@ inline int dtp_halo_variant(int tile) { return tile >= 48 ? tile - 44 : tile - 1
 constexpr int DTP_TILE_LNLIN = 50;  // lnlin_kernel (lnlin.hip): the "splits" of a tune entry are its column ranges, K is not split
 constexpr int DTP_TILE_WS0 = 51;    // convws_kernel (conv_ws.hip): 51 = three 8 x 8 images, 52 = one 16 x 16 image, 53 = an 8 x 16 pixel tile x 64 channels per workgroup, 54 = the same for two co-resident workgroups per CU; splits = K-slices
 constexpr int DTP_WS_VARIANTS = 4;
-constexpr int DTP_TILE_IDS = 55;    // tile ids are 0 .. DTP_TILE_IDS - 1
+constexpr int DTP_TILE_GEMMWS = 55; // gemmws_kernel (gemm_ws.hip): dense problems with the fragment-order packing; splits = K-slices
+constexpr int DTP_TILE_IDS = 56;    // tile ids are 0 .. DTP_TILE_IDS - 1
 inline bool dtp_is_ws_tile(int tile) { return tile >= DTP_TILE_WS0 && tile < DTP_TILE_WS0 + DTP_WS_VARIANTS; }
 // Split-K of a problem of nkb 64-wide k-blocks into (at most) sp slices.  conv_halo_kernel unrolls the nine taps of a channel block:
 // its slices are multiples of 9 k-blocks (the 9 * Cin/64 conv blocks come first, so no channel block is cut).
 inline void dtp_split_k(int nkb, int tile, int sp, int* kb_per_split, int* splits) {
   if (sp < 1) sp = 1;
   if (tile == DTP_TILE_LNLIN) { *kb_per_split = nkb; *splits = 1; return; }
-  if (dtp_is_ws_tile(tile)) { *kb_per_split = (nkb + sp - 1) / sp; *splits = sp; return; }  // slices are ranges of whole channel blocks (conv_ws.hip)
+  if (dtp_is_ws_tile(tile) || tile == DTP_TILE_GEMMWS) { *kb_per_split = (nkb + sp - 1) / sp; *splits = sp; return; }  // slices are ranges of whole channel / k-blocks (conv_ws.hip, gemm_ws.hip)
   int kbps = (nkb + sp - 1) / sp;
   if (dtp_is_halo_tile(tile) && sp > 1) kbps = (((nkb + 8) / 9 + sp - 1) / sp) * 9;
   *kb_per_split = kbps;
@@ -323,6 +325,12 @@ int dtp_launch_conv_ws(const GemmParams& p, int variant, hipStream_t s);
 void dtp_conv_ws_init();
 size_t dtp_conv_ws_packed_elems(int Cout, int Cin, int Cin2);
 int dtp_launch_pack_conv_ws(const float* w, const float* w1, f16* out, int Cout, int Cin, int Cin2, hipStream_t s);
+// gemm_ws.hip: weight-streaming dense GEMM (64 x 64 per workgroup, the waves split the contraction by k-blocks)
+bool dtp_gemm_ws_supported(const GemmParams& p, int nsplit);
+int dtp_launch_gemm_ws(const GemmParams& p, hipStream_t s);
+void dtp_gemm_ws_init();
+size_t dtp_gemm_ws_packed_elems(int N, int K);
+int dtp_launch_pack_linear_ws(const f16* w, int ldw, f16* out, int N, int K, hipStream_t s);
 bool dtp_conv_halo_supported(const GemmParams& p);
 bool dtp_conv_halo3_supported(const GemmParams& p);  // variants 4 / 5 (tile ids 48 / 49): three images per workgroup
 int dtp_launch_conv_halo(const GemmParams& p, int variant, hipStream_t s);

@@ -26,7 +26,8 @@ struct Staged {
 struct ConvW {  // 3x3 (taps = 9) or 1x1 (taps = 1) convolution / any Linear (taps = 1)
   f16* w = nullptr;
   f16* wcb = nullptr;  // 3x3 only: channel-block-major packing for conv_halo_kernel (Cin % 64 == 0, no fused shortcut)
-  f16* wfr = nullptr;  // 3x3 of the UNet only: MFMA-fragment-order packing for convws_kernel (conv_ws.hip; Cin % 64 == 0, the 3x3 part)
+  f16* wfr = nullptr;  // UNet only: MFMA-fragment-order packing -- of a 3x3 conv for convws_kernel (conv_ws.hip; Cin % 64 == 0, + the fused shortcut),
+                       // of a Linear for gemmws_kernel (gemm_ws.hip; K % 64 == 0)
   float* b = nullptr;  // fp32 bias (may be null)
   float* lns = nullptr;  // LayerNorm folded in: row sums of the packed weights (GF_LNFOLD)
   int cout = 0, cin = 0 /* padded */, cin_true = 0, taps = 1, K = 0, ldw = 0;
@@ -52,7 +53,7 @@ struct Ctx;
 // A launch program: a flat list of closures bound to statically planned buffers.
 using Op = std::function<int(hipStream_t, int /*step*/)>;
 // profiling classes (dtp_profile_rows): 0-11 = gemm_kernel<BM,BN,NS> variants (id = shape + 4*(NS-2)), then the rest
-enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_BIG0 = 21, PK_WIDE0 = 25, PK_FP8 = 27, PK_KH2 = 28, PK_LW = 36, PK_XATTN = 44, PK_HALO3 = 45, PK_LNLIN = 47, PK_WS0 = 48, PK_COUNT = 52 };
+enum { PK_GEMM0 = 0, PK_ATTN = 12, PK_GN = 13, PK_LN = 14, PK_ELEM = 15, PK_SOFTMAX = 16, PK_HALO0 = 17, PK_BIG0 = 21, PK_WIDE0 = 25, PK_FP8 = 27, PK_KH2 = 28, PK_LW = 36, PK_XATTN = 44, PK_HALO3 = 45, PK_LNLIN = 47, PK_WS0 = 48, PK_GEMMWS = 52, PK_COUNT = 53 };
 struct ProfRec {
   int kind;
   double flops, bytes;

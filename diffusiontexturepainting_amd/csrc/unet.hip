@@ -308,7 +308,7 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
     }
     GemmParams g = {};
     g.A = f.p; g.lda = f.ld; g.A2 = y3.p; g.lda2 = y3.ld; g.Cin2 = y3.C;
-    g.W = wm.w; g.ldw = wm.ldw; g.nkb = wm.ldw / 64;
+    g.W = wm.w; g.Wfr = wm.wfr; g.ldw = wm.ldw; g.nkb = wm.ldw / 64;
     g.M = N * S; g.N = C; g.K = wm.K;
     g.C = out.p; g.ldc = out.ld;
     g.bias = wm.b; g.R = xin.p; g.ldr = xin.ld;

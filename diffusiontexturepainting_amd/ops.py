@@ -64,6 +64,14 @@ def pack_conv_ws(w, w1=None):
     return out
 
 
+def pack_linear_ws(wp, n, k):
+    """wp: packed f16 rows of pack_linear (k % 64 == 0) -> the MFMA-fragment-order copy gemmws_kernel streams (tile id 55)."""
+    lib = _lib.load()
+    out = torch.zeros(lib.dtp_op_pack_linear_ws_elems(n, k), dtype=torch.float16, device=wp.device)
+    check(lib.dtp_op_pack_linear_ws(ptr(wp), wp.stride(0), ptr(out), n, k, _stream()), "pack_linear_ws")
+    return out
+
+
 def rowsum(wp, k):
     """fp32 row sums of packed fp16 weights over the first k columns (the `lns` vector of a LayerNorm-folded GEMM)."""
     lib = _lib.load()
@@ -82,7 +90,8 @@ def quantize_w8(wp, k):
 
 
 def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, out=None, lda=None, lns=None, ln_eps=1e-5, batch=0,
-         sm_valid=0, bias_shared=False, tail=None, row_stats=False, stats_in=None, w8=None, w_scale=1.0, a_scale=1.0, layernorm=False):
+         sm_valid=0, bias_shared=False, tail=None, row_stats=False, stats_in=None, w8=None, w_scale=1.0, a_scale=1.0, layernorm=False,
+         wfr=None):
     """a f16 [M, >=K] row-major; wp packed weights; returns f16 [M, N] (or [M, N/2] with GEGLU).
     batch > 1: a is [batch*M, K] (problem b = rows b*M..), wp is [batch*Npad, Kpad], bias / lns are [batch*Npad]."""
     lib = _lib.load()
@@ -116,6 +125,8 @@ def gemm(a, wp, n, k=None, bias=None, resid=None, flags=0, tile=-1, splits=0, ou
         if layernorm:
             d.flags |= GF_LNFOLD
             d.ln_eps = ln_eps
+    if wfr is not None:  # tile 55: the fragment-order copy of wp (pack_linear_ws)
+        d.Wfr = wfr.data_ptr()
     st = None
     if row_stats:  # also return the per-row (sum, sumsq) partials of the fp16 output: f32 [parts, M, 2]
         st = torch.zeros((n + 63) // 64, a.shape[0], 2, dtype=torch.float32, device=a.device)

@@ -128,7 +128,8 @@ int dtp_last_stamp_info(dtp_ctx* ctx, int* unet_evals, int* graph_nodes);
  * 28-35 = gemm_kernel<BM,BN,NS,2> (the 8-wave twins of shapes 0..3 at 2 / 3 stages), 36-43 = gemm_kernel<BM,BN,3,1,LW> (4 / 8 loader
  * waves), 44 = xattn_kernel (fused cross-attention GEMM pair), 45-46 = conv_halo_kernel<8,8,64|128> with three images per workgroup,
  * 47 = lnlin_kernel (activation-stationary LayerNorm-folded Linear / GEGLU), 48-51 = convws_kernel (weight-streaming 3x3 conv:
- * three 8x8 images / one 16x16 image / an 8x16 pixel tile x 64 channels per workgroup / the same for two workgroups per CU).  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
+ * three 8x8 images / one 16x16 image / an 8x16 pixel tile x 64 channels per workgroup / the same for two workgroups per CU),
+ * 52 = gemmws_kernel (weight-streaming dense GEMM).  flops/bytes are ALGORITHMIC (unpadded 2*M*N*K; each operand once in fp16).
  * dtp_profile(ctx, 0) switches back to graph replay.  The nvtx/cudaEvent hooks of
  * stable_diffusion_pipeline.py:146-149,486-503 are the reference counterpart. */
 typedef struct { int kind; int launches; double ms; double flops; double bytes; } dtp_prof_row;
@@ -201,7 +202,7 @@ typedef struct {
   int gn_cpg;        /* DTP_GF_GNSTATS (tiles 53 / 54, unsplit): channels per group of the GroupNorm that consumes the output; st_out then
                         receives f32 [images][2 * (Ho/8) * (Wo/16)][N / gn_cpg][2] partial (sum, sum of squares) of the rounded outputs,
                         the input of dtp_op_groupnorm_apply */
-  const void* Wfr;   /* 3x3 conv, tiles 51 .. 54: the weights in MFMA fragment order (dtp_op_pack_conv_ws) */
+  const void* Wfr;   /* 3x3 conv, tiles 51 .. 54: the weights in MFMA fragment order (dtp_op_pack_conv_ws); dense, tile 55: dtp_op_pack_linear_ws */
 } dtp_gemm_desc;
 enum { DTP_GF_BIAS = 1, DTP_GF_BIAS_M = 2, DTP_GF_RESID = 4, DTP_GF_GEGLU = 8, DTP_GF_GELU = 64, DTP_GF_QUICKGELU = 128,
        DTP_GF_OUT_F32 = 256, DTP_GF_SILU = 512, DTP_GF_LNFOLD = 1024, DTP_GF_ROWSTATS = 2048, DTP_GF_SOFTMAX16 = 4096,
@@ -224,6 +225,10 @@ int dtp_op_pack_conv_cb(const float* w, void* out, int Cout, int Cin, int ldw, d
  * or f32 [Cout][Cin2], Cin2 % 64 == 0) = the 1x1 weights of a fused shortcut (desc.A2), packed behind them */
 int dtp_op_pack_conv_ws(const float* w, const float* w1, void* out, int Cout, int Cin, int Cin2, dtp_stream s);
 long long dtp_op_pack_conv_ws_elems(int Cout, int Cin, int Cin2);
+/* w f16: the packed rows [>= N][ldw] of dtp_op_pack_linear (K % 64 == 0) -> out f16, dtp_op_pack_linear_ws_elems(N, K) elements: 1 KB
+   fragments (32-column n-tile, 64-wide k-block, 16-wide k-step) in the order the weight-streaming GEMM (tile 55) loads them */
+int dtp_op_pack_linear_ws(const void* w, int ldw, void* out, int N, int K, dtp_stream s);
+long long dtp_op_pack_linear_ws_elems(int N, int K);
 int dtp_op_groupnorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
                      int groups, float eps, int silu, dtp_stream s);
 /* the apply pass of the two-launch GroupNorm on partial sums f32 [B][nchunk][groups][2] that a producer emitted (a convws_kernel launch

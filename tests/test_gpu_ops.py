@@ -181,6 +181,60 @@ def test_lnlin_plain_variant_bias_residual_rowstats_grouped(ops, m, c, n, ranges
     assert (got.float() - other.float()).abs().max().item() <= 1e-2 * max(1.0, other.float().abs().max().item())
 
 
+@pytest.mark.parametrize("m,k,n,splits,tail", [(768, 1280, 1280, 1, 0), (768, 1280, 3840, 1, 0), (3072, 2560, 640, 1, 640), (192, 1280, 1280, 4, 0),
+                                                (100, 128, 96, 1, 0), (333, 704, 320, 3, 64), (64, 6400, 64, 5, 1280), (12288, 1280, 320, 1, 320)])
+def test_gemm_weight_streaming_kernel(ops, m, k, n, splits, tail):
+    """gemmws_kernel (tile id 55: weights in fragment order straight into registers, the four waves split the contraction by k-blocks,
+    wave-private activation rings): out = [A | A2] W^T + bias + R with the row statistics of the stored values; ragged row tiles, an
+    odd n-tile count (N = 96), waves without a k-block (K = 128), K-slices with fp32 slabs, the two-operand contraction."""
+    ka = k - tail
+    x = rnd(m, ka, seed=230)
+    x2 = rnd(m, tail, seed=231) if tail else None
+    res = rnd(m, n, seed=232)
+    w = rnd(n, k, seed=233, scale=k ** -0.5).float()
+    bias = 0.1 * torch.randn(n, generator=torch.Generator().manual_seed(234))
+    xa = torch.cat([x, x2], dim=1) if tail else x
+    ref = F.linear(xa.float(), w, bias) + res.float()
+    wp = ops.pack_linear(w.cuda())
+    wfr = ops.pack_linear_ws(wp, n, k)
+    bp = torch.zeros(wp.shape[0])
+    bp[:n] = bias
+    kw = dict(bias=bp.cuda(), resid=res.cuda(), tail=x2.cuda() if tail else None)
+    got, st = ops.gemm(x.cuda(), wp, n, ka, tile=55, splits=splits, wfr=wfr, row_stats=True, **kw)
+    close(got, ref, tol=3e-3)
+    gf = got.float().cpu()
+    want = torch.stack([gf.sum(dim=1), (gf * gf).sum(dim=1)], dim=-1)
+    assert st.shape[0] == (1 if splits > 1 else (n + 63) // 64)
+    assert torch.allclose(st.sum(dim=0).cpu(), want, rtol=1e-3, atol=5e-2)
+    other = ops.gemm(x.cuda(), wp, n, ka, tile=2, **kw)
+    assert (got.float() - other.float()).abs().max().item() <= 1e-2 * max(1.0, other.float().abs().max().item())
+    again, _ = ops.gemm(x.cuda(), wp, n, ka, tile=55, splits=splits, wfr=wfr, row_stats=True, **kw)
+    assert torch.equal(got, again)  # fixed summation order
+
+
+@pytest.mark.parametrize("m,c,n", [(768, 1280, 3840), (192, 1280, 1280), (500, 640, 320)])
+def test_gemm_weight_streaming_layernorm_fold(ops, m, c, n):
+    """gemmws_kernel with GF_LNFOLD: the raw pre-LayerNorm rows, gamma folded into W, statistics from the producer's per-range
+    partials (here: three synthetic partials per row that add up to the row sums)."""
+    x = rnd(m, c, seed=240) * 1.5 + 0.3
+    w = rnd(n, c, seed=241, scale=c ** -0.5).float()
+    g = torch.Generator().manual_seed(242)
+    gamma, beta, bias = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(n, generator=g)
+    ref = F.linear(F.layer_norm(x.float(), (c,), gamma, beta, 1e-5), w, bias)
+    wp = ops.pack_linear((w * gamma[None]).cuda())
+    wfr = ops.pack_linear_ws(wp, n, c)
+    lns = ops.rowsum(wp, c)
+    b2 = torch.zeros(wp.shape[0])
+    b2[:n] = bias + w @ beta
+    xf = x.float()
+    tot = torch.stack([xf.sum(dim=1), (xf * xf).sum(dim=1)], dim=-1)
+    parts = torch.stack([0.5 * tot, 0.3 * tot, 0.2 * tot]).contiguous().cuda()
+    got = ops.gemm(x.cuda(), wp, n, c, bias=b2.cuda(), lns=lns, stats_in=parts, tile=55, wfr=wfr)
+    close(got, ref, tol=3e-3)
+    other = ops.gemm(x.cuda(), wp, n, c, bias=b2.cuda(), lns=lns, stats_in=parts, tile=2)
+    assert (got.float() - other.float()).abs().max().item() <= 1e-2 * max(1.0, other.float().abs().max().item())
+
+
 @pytest.mark.parametrize("tile", [-1, 2, 5, 8, 33, 34, 39, 41, 46])
 def test_gemm_batched_group_softmax(ops, tile):
     """Grouped GEMM (one weight matrix per batch entry) + LayerNorm fold + softmax over groups of 16 columns (14 valid):
