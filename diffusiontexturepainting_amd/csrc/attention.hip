@@ -35,16 +35,18 @@ namespace {
 
 // OCC4: compile for four waves per SIMD (128 registers instead of 130): 4.7 % faster on the batched level-0 launch (6144
 // workgroups: 922 -> 879 us), 2 % slower when the whole grid is co-resident at three anyway (768 workgroups at batch 1)
-template <int DP, bool SHIFT = false, bool OCC4 = false>  // SHIFT: d = 40 in a 48-wide contraction (see the header comment)
-__global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)))) void attention_kernel(const AttnParams p) {
+// NW: waves (32 query rows each) per workgroup; 8 = one K / V^T tile staged for 256 queries (the batched level-0 launch, see the launcher)
+template <int DP, bool SHIFT = false, bool OCC4 = false, int NW = 4>  // SHIFT: d = 40 in a 48-wide contraction (see the header comment)
+__global__ __launch_bounds__(64 * NW, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)))) void attention_kernel(const AttnParams p) {
+  constexpr int NTHR = 64 * NW;
   static_assert(!SHIFT || DP == 48, "the shift column lives in the padding of d = 40");
   constexpr int KS = DP / 16;           // k-steps of the QK^T contraction
   constexpr int DB = (DP + 31) / 32;    // 32-row blocks of O^T
   constexpr int KROW = DP * 2 + 16;     // K tile row stride (bytes): odd multiple of 16 -> conflict free
   constexpr int VROW = 64 * 2 + 16;     // V^T tile row stride (bytes)
   constexpr int NCH = DP / 8;
-  constexpr int KIT = (64 * NCH + 255) / 256;  // K chunks per thread per tile
-  constexpr int VIT = (32 * NCH + 255) / 256;  // V key-pair chunks per thread per tile
+  constexpr int KIT = (64 * NCH + NTHR - 1) / NTHR;  // K chunks per thread per tile
+  constexpr int VIT = (32 * NCH + NTHR - 1) / NTHR;  // V key-pair chunks per thread per tile
   // One K / V^T tile buffer, two barriers per 64-key tile.  (Measured: double-buffering the tiles -- one barrier, the next
   // tile written right after this tile's MFMAs -- was 15 % SLOWER on the level-0 shape: 139 vs 118 us.)
   constexpr int KBYTES = 64 * KROW, VBYTES = DB * 32 * VROW;
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
   // kernel is VALU-issue-bound, not K / V-fetch-bound; a grid that walks all heads per query block thrashes: 757 -> 1454 us at batch 8)
   const int h = blockIdx.y, b = blockIdx.z, qblk = blockIdx.x;
   const int D = p.D;
-  const int q = qblk * 128 + wave * 32 + lq;
+  const int q = qblk * (32 * NW) + wave * 32 + lq;
   const f16* Qb = p.Q + p.qbs * b + h * D;
   const f16* Kb = p.K + p.kbs * b + h * D;
   const f16* Vb = p.V + p.vbs * b + h * D;
@@ -90,8 +92,8 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
   float m_run = SHIFT ? 0.f : NEG, l_run = 0.f;  // SHIFT: m_run is the fp16-representable reference carried in Q'[40]
 
   // zero the V^T tile once: rows d >= D are never written by the staging loop
-  for (int i = tid; i < NBUF * VBYTES / 16; i += 256) ((f32x4*)Vl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int i = tid; i < NBUF * KBYTES / 16; i += 256) ((f32x4*)Kl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // padding columns stay zero
+  for (int i = tid; i < NBUF * VBYTES / 16; i += NTHR) ((f32x4*)Vl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < NBUF * KBYTES / 16; i += NTHR) ((f32x4*)Kl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // padding columns stay zero
   if (ONES || SHIFT) {
     __syncthreads();
     for (int b2 = 0; b2 < NBUF; ++b2) {
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
   const f16* ksrc[KIT]; bool kval[KIT]; int kkv[KIT];
 #pragma unroll
   for (int it = 0; it < KIT; ++it) {
-    const int idx = tid + it * 256;
+    const int idx = tid + it * NTHR;
     const int kv = idx / NCH, c = idx - kv * NCH;
     kval[it] = (idx < 64 * NCH) && (c * 8 < D);
     kkv[it] = kval[it] ? kv : 0;   // threads without a chunk all read the tile's first 16 bytes (one line, broadcast)
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
   const f16* vsrc[VIT]; bool vval[VIT]; int vkv[VIT];
 #pragma unroll
   for (int it = 0; it < VIT; ++it) {
-    const int idx = tid + it * 256;
+    const int idx = tid + it * NTHR;
     const int c = idx >> 5, pr = idx & 31;
     vval[it] = (c < NCH) && (c * 8 < D);
     vkv[it] = vval[it] ? 2 * pr : 0;
@@ -154,17 +156,21 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
     }
   };
   auto stage = [&](int buf) {
+#ifdef DTP_ATTN_NO_STAGE
+    asm volatile("" ::"v"(kreg[0]), "v"(vreg[0][0]), "v"(vreg[0][1]));
+    return;
+#endif
     char* const Kd = Kl + buf * KBYTES;
     char* const Vd = Vl + buf * VBYTES;
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
-      const int idx = tid + it * 256;
+      const int idx = tid + it * NTHR;
       const int kv = idx / NCH, c = idx - kv * NCH;
       if (kval[it]) *(f16x8*)(Kd + kv * KROW + c * 16) = kreg[it];
     }
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {
-      const int idx = tid + it * 256;
+      const int idx = tid + it * NTHR;
       const int c = idx >> 5, pr = idx & 31;
       if (vval[it]) {
         const int o = (2 * pr) & 15;
@@ -211,8 +217,18 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
+#ifndef DTP_ATTN_NO_LDSREAD  // (diagnostic builds only: tools/attn_variants.sh)
         const f16x8 kf = *(const f16x8*)(kfrag + kb * 32 * KROW + ks * 32);  // immediate offsets off one per-lane base
+#else
+        f16x8 kf = qf[ks];
+        asm volatile("" : "+v"(kf));
+#endif
+#ifndef DTP_ATTN_NO_MFMA
         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : sacc[kb], 0, 0, 0);
+#else
+        if (ks == 0) sacc[kb] = zero16;
+        asm volatile("" : "+v"(sacc[kb]) : "v"(kf), "v"(qf[ks]));
+#endif
       }
     }
     if (p.prio) __builtin_amdgcn_s_setprio(0);
@@ -261,7 +277,11 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
           u32x4 w;
 #pragma unroll
           for (int e = 0; e < 8; e += 2) {
+#ifndef DTP_ATTN_NO_EXP
             const float p0 = __builtin_amdgcn_exp2f(sacc[kb][8 * s + e]), p1 = __builtin_amdgcn_exp2f(sacc[kb][8 * s + e + 1]);
+#else
+            const float p0 = sacc[kb][8 * s + e], p1 = sacc[kb][8 * s + e + 1];
+#endif
             w[e >> 1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(p0, p1));  // one v_cvt_pkrtz_f16_f32 per pair
           }
           pf[kb][s] = __builtin_bit_cast(f16x8, w);
@@ -297,8 +317,17 @@ __global__ __launch_bounds__(256, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 : 1)
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+#ifndef DTP_ATTN_NO_LDSREAD
           const f16x8 vf = *(const f16x8*)(vfrag + db * 32 * VROW + (kb * 32 + 16 * s) * 2);
+#else
+          f16x8 vf = pf[kb][s];
+          asm volatile("" : "+v"(vf));
+#endif
+#ifndef DTP_ATTN_NO_MFMA
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s], oacc[db], 0, 0, 0);
+#else
+          asm volatile("" : "+v"(oacc[db]) : "v"(vf), "v"(pf[kb][s]));
+#endif
         }
     }
     if (p.prio & 2) __builtin_amdgcn_s_setprio(0);
@@ -350,6 +379,14 @@ int dtp_launch_attention(const AttnParams& pin, hipStream_t s) {
     return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }();
   const bool many = (long long)grid.x * grid.y * grid.z > 3LL * cus;  // more workgroups than fit at three waves per SIMD
+  // eight-wave workgroups stage every K / V^T tile for 256 queries instead of 128 (the staging -- LDS stores and the two barriers around
+  // them -- is a third of the level-0 launch: profiles/r04_attention_ablation.txt); only when that still leaves every CU its share
+  static const int nw8_env = [] { const char* e = getenv("DTP_ATTN_NW8"); return e ? atoi(e) : -1; }();
+  const bool nw8 = nw8_env >= 0 ? nw8_env != 0 : (long long)((p.Sq + 255) / 256) * grid.y * grid.z >= 8LL * cus;
+  if (p.D == 40 && many && nw8) {
+    hipLaunchKernelGGL((attention_kernel<48, true, true, 8>), dim3((p.Sq + 255) / 256, p.H, p.B), dim3(512), 0, s, p);
+    return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
+  }
   if (p.D == 40 && many) hipLaunchKernelGGL((attention_kernel<48, true, true>), grid, block, 0, s, p);
   else if (p.D == 40) hipLaunchKernelGGL((attention_kernel<48, true>), grid, block, 0, s, p);
   else if (p.D <= 48) hipLaunchKernelGGL((attention_kernel<48>), grid, block, 0, s, p);

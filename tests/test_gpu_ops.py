@@ -645,6 +645,19 @@ def test_attention_fused_qkv_views_and_peaked_softmax(ops):
     close(got, ref, tol=3e-3)
 
 
+def test_attention_eight_wave_workgroups_on_a_batched_launch(ops):
+    """A launch with >= 8 x CUs 256-query blocks (here 130 samples x 8 heads x 2 blocks) takes the eight-wave build of the d = 40 kernel
+    (one K / V^T tile staged for 256 queries); ragged last query block and last key tile, fused-buffer views, a dominant late key."""
+    b, s, heads, d = 130, 500, 8, 40
+    c = heads * d
+    qkv = rnd(b, s, 3 * c, seed=75)
+    qkv[:, 470, c:2 * c] *= 5.0
+    ref = _attn_ref(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], heads)
+    g = qkv.cuda()
+    got = ops.attention(g[..., :c], g[..., c:2 * c], g[..., 2 * c:], heads)
+    close(got, ref, tol=3e-3)
+
+
 def test_softmax_rows(ops):
     x = rnd(300, 4096, seed=80) * 3
     ref = torch.softmax(x.float() * 0.21, dim=-1)
