@@ -199,17 +199,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     // 20 k-steps; fragments four k-steps ahead; one DMA piece of unit u + 2 every fourth MFMA
     f16x8 wf[4];
 #pragma unroll
+#ifndef DTP_LNLIN_NO_LDSREAD  // (diagnostic builds only: tools/lnlin_variants.sh)
     for (int s = 0; s < 4; ++s) wf[s] = lds_read16(xs[s]);
+#define DTP_LNLIN_RD(ks) wf[(ks) & 3] = lds_read16_off<(((ks) + 4) >> 2) * 4096>(xs[(ks) & 3])
+#define DTP_LNLIN_WAIT(ks)                                                                                    \
+      if constexpr ((ks) < 16) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wf[(ks) & 3]));                     \
+      else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[(ks) & 3]) : "n"(19 - (ks)))
+#else
+    for (int s = 0; s < 4; ++s) { wf[s] = af[s]; asm volatile("" : "+v"(wf[s]) : "v"(xs[s])); }
+#define DTP_LNLIN_RD(ks) asm volatile("" : "+v"(wf[(ks) & 3]))
+#define DTP_LNLIN_WAIT(ks) asm volatile("" : "+v"(wf[(ks) & 3]))
+#endif
+#ifndef DTP_LNLIN_NO_MFMA
+#define DTP_LNLIN_MFMA(acc, ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(ks) & 3], af[PART * 20 + (ks)], acc, 0, 0, 0)
+#else
+#define DTP_LNLIN_MFMA(acc, ks) asm volatile("" : "+v"(acc) : "v"(wf[(ks) & 3]), "v"(af[PART * 20 + (ks)]))
+#endif
 #define DTP_STEP(ks)                                                                                          \
     {                                                                                                         \
       __builtin_amdgcn_sched_barrier(0);                                                                      \
-      if constexpr ((ks) < 16) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wf[(ks) & 3]));                     \
-      else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[(ks) & 3]) : "n"(19 - (ks)));                       \
-      if constexpr (SEL == 1) acc_g = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(ks) & 3], af[PART * 20 + (ks)], acc_g, 0, 0, 0); \
-      else acc_a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[(ks) & 3], af[PART * 20 + (ks)], acc_a, 0, 0, 0); \
+      DTP_LNLIN_WAIT(ks);                                                                                     \
+      if constexpr (SEL == 1) { DTP_LNLIN_MFMA(acc_g, ks); } else { DTP_LNLIN_MFMA(acc_a, ks); }              \
       if constexpr ((ks) + 4 < 20) {                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        wf[(ks) & 3] = lds_read16_off<(((ks) + 4) >> 2) * 4096>(xs[(ks) & 3]);                                \
+        DTP_LNLIN_RD(ks);                                                                                     \
       }                                                                                                       \
       if constexpr (((ks) & 3) == 1) {                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -220,6 +233,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     DTP_STEP(0) DTP_STEP(1) DTP_STEP(2) DTP_STEP(3) DTP_STEP(4) DTP_STEP(5) DTP_STEP(6) DTP_STEP(7) DTP_STEP(8) DTP_STEP(9)
     DTP_STEP(10) DTP_STEP(11) DTP_STEP(12) DTP_STEP(13) DTP_STEP(14) DTP_STEP(15) DTP_STEP(16) DTP_STEP(17) DTP_STEP(18) DTP_STEP(19)
 #undef DTP_STEP
+#undef DTP_LNLIN_RD
+#undef DTP_LNLIN_WAIT
+#undef DTP_LNLIN_MFMA
     slot = (slot == 2) ? 0 : slot + 1;
     ++u;
   };
@@ -247,7 +263,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
           for (int e = 0; e < 4; ++e) {
             const float av = rstd * (acc_a[4 * q + e] - mean * la[e]) + ba[e];
             const float gv = rstd * (acc_g[4 * q + e] - mean * lg[e]) + bg[e];
+#ifndef DTP_LNLIN_NO_GELU
             o[e] = (f16)(av * gelu_erf(gv));
+#else
+            o[e] = (f16)(av * gv);
+#endif
           }
         } else if constexpr (LN) {
 #pragma unroll
