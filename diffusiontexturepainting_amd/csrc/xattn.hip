@@ -16,10 +16,14 @@
 
 namespace {
 
-__device__ __forceinline__ void glds16(const void* src, void* lds_uniform) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
+template <int OFF>
+__device__ __forceinline__ f16x8 lds_read16_off(uint32_t addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
 }
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int XBM = 64, XBN = 128;              // rows per workgroup; columns of both phases' tiles
 constexpr int XSTAGE = (XBM + XBN) * 128;       // one phase-1 k-block: 64 activation rows + 128 W1 rows
@@ -46,29 +50,67 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
   const f16* W2 = p.W2 + (size_t)smp * p.w2_bs;
   const size_t row0 = (size_t)smp * p.S;         // first global row of this sample (statistics tables, output)
 
+  // ---- the epilogue's per-thread operands first: bias chunk and the residual rows of this thread's four output chunks (clamped rows:
+  // unconditional loads).  Requested before any DMA, consumed after phase 2 -- loaded there they cost one exposed L2 round trip at
+  // the very end of every launch.
+  constexpr int NC = XBN / 8;  // 16: a thread owns the same 8-column chunk in every epilogue iteration
+  constexpr int EIT = XBM * NC / 256;  // 4
+  const int nc = tid % NC;
+  const int n = n0 + nc * 8;
+  const bool col_ok = (n + 8 <= p.C);  // C % 8 == 0
+  float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (col_ok && p.b2) {
+    const f32x4 t0 = *(const f32x4*)(p.b2 + n), t1 = *(const f32x4*)(p.b2 + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bv[e] = t0[e]; bv[4 + e] = t1[e]; }
+  }
+  // (epilogue 1: this thread's chunk of the per-sample score bias and weight row sums)
+  const f32x4 e1b0 = *(const f32x4*)(p.b1 + (size_t)smp * 128 + nc * 8), e1b1 = *(const f32x4*)(p.b1 + (size_t)smp * 128 + nc * 8 + 4);
+  const f32x4 e1l0 = *(const f32x4*)(p.lns1 + (size_t)smp * 128 + nc * 8), e1l1 = *(const f32x4*)(p.lns1 + (size_t)smp * 128 + nc * 8 + 4);
+  f16x8 rv[EIT];
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) {
+    const int mr = min(m0 + (tid + it * 256) / NC, p.S - 1);
+    rv[it] = col_ok ? *(const f16x8*)(p.R + (row0 + mr) * p.ldr + n) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+
   // ---- DMA sources.  LDS row r = i*32 + wave*8 + (lane>>3); slot lane&7 holds source chunk slot ^ ((r>>1)&7)
   const int lrow = wave * 8 + (lane >> 3);
   const int kc = (((lane & 7) ^ ((lrow >> 1) & 7)) << 3);
-  const f16* a_row[2];
+  // Buffer-addressed LDS-DMA (buffer_load_dwordx4 ... lds): loop-constant 32-bit lane offsets, the k-block as a scalar offset -- no
+  // 64-bit address arithmetic per piece (round 4: the global_load_lds form it replaces was most of a k-block's issue time).  Rows
+  // beyond S carry an out-of-range offset: the DMA writes zeros.
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)0x80000000u, 0x00020000);
+  const auto rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)W1, 0, (int)0x80000000u, 0x00020000);
+  const auto rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)W2, 0, (int)0x80000000u, 0x00020000);
+  int a_off[2], w1_off[4];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + i * 32 + lrow;
-    a_row[i] = (m < p.S) ? X + (size_t)m * p.ldx + kc : nullptr;
+    a_off[i] = (m < p.S) ? (m * p.ldx + kc) * 2 : -1;
   }
-  const f16* w1_row[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w1_row[i] = W1 + (size_t)(i * 32 + lrow) * p.C + kc;
+  for (int i = 0; i < 4; ++i) w1_off[i] = ((i * 32 + lrow) * p.C + kc) * 2;
   // the whole W2 tile now: it lands while phase 1 runs (rows beyond C are zero padding of the per-sample matrices)
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(W2 + (size_t)(n0 + i * 32 + lrow) * 128 + kb * 64 + kc, w2s + kb * (XBN * 128) + (i * 32 + wave * 8) * 128);
+    for (int i = 0; i < 4; ++i) {
+      const int vo = ((n0 + i * 32 + lrow) * 128 + kc) * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (lds_ptr_t)(w2s + kb * (XBN * 128) + (i * 32 + wave * 8) * 128), 16, vo, kb * 128, 0, 0);
+    }
   auto issue = [&](int stage, int kb) {
     char* As = ring + stage * XSTAGE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(a_row[i] ? a_row[i] + (size_t)kb * 64 : p.zero, As + (i * 32 + wave * 8) * 128);
+    for (int i = 0; i < 2; ++i) {
+      const int vo = a_off[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(As + (i * 32 + wave * 8) * 128), 16, vo, kb * 128, 0, 0);
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(w1_row[i] + (size_t)kb * 64, As + XBM * 128 + (i * 32 + wave * 8) * 128);
+    for (int i = 0; i < 4; ++i) {
+      const int vo = w1_off[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (lds_ptr_t)(As + XBM * 128 + (i * 32 + wave * 8) * 128), 16, vo, kb * 128, 0, 0);
+    }
   };
   const int nkb = p.C >> 6;
 #pragma unroll
@@ -92,20 +134,33 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  // one 64-wide k-block of a [64 rows | 128 rows] image pair: weight fragment = MFMA A operand, activation fragment = B operand
-  auto kblock = [&](const char* As, const char* Ws) {
+  // one 64-wide k-block of a [64 rows | 128 rows] image pair: weight fragment = MFMA A operand, activation fragment = B operand.
+  // All twelve fragment reads of the k-block are requested up front (untracked ds_read_b128, hand-counted lgkmcnt: with LDS-DMA in the
+  // loop hipcc only ever waits lgkmcnt(0), i.e. one exposed LDS round trip per MFMA -- 8 per k-block with a single wave per SIMD and
+  // nothing to hide them: 0.5 of the 0.6 us a k-block took).  Request order: (a, w0, w1) of k-step 0, 1, 2, 3.
+  uint32_t xa[4], xw[4];  // per-lane byte addresses inside a stage: activation row wm0 + frow, weight row wn0 + frow (+ 32 rows = +4096)
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c = ks * 2 + fhalf;
+    const int ar = wm0 + frow, wr = wn0 + frow;
+    xa[ks] = lds_addr(ring) + ar * 128 + ((c ^ ((ar >> 1) & 7)) << 4);
+    xw[ks] = lds_addr(ring) + wr * 128 + ((c ^ ((wr >> 1) & 7)) << 4);
+  }
+  auto kblock = [&](uint32_t ao, uint32_t wo) {  // byte offsets (from the ring's base) of the activation and the weight image
+    f16x8 af[4], wf[4][2];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int c = ks * 2 + fhalf;
-      const int ar = wm0 + frow;
-      const f16x8 af = *(const f16x8*)(As + ar * 128 + ((c ^ ((ar >> 1) & 7)) << 4));
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int wr = wn0 + i * 32 + frow;
-        const f16x8 wf = *(const f16x8*)(Ws + wr * 128 + ((c ^ ((wr >> 1) & 7)) << 4));
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[i], 0, 0, 0);
-      }
+      af[ks] = lds_read16(xa[ks] + ao);
+      wf[ks][0] = lds_read16(xw[ks] + wo);
+      wf[ks][1] = lds_read16_off<4096>(xw[ks] + wo);
     }
+#define DTP_XA_STEP(ks)                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(af[ks]), "+v"(wf[ks][0]) : "n"(10 - 3 * (ks)));                          \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][0], af[ks], acc[0], 0, 0, 0);                                 \
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[ks][1]) : "n"(9 - 3 * (ks)));                                         \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][1], af[ks], acc[1], 0, 0, 0);
+    DTP_XA_STEP(0) DTP_XA_STEP(1) DTP_XA_STEP(2) DTP_XA_STEP(3)
+#undef DTP_XA_STEP
   };
 
   // ---- phase 1: S = X W1^T over K = C; XNS-deep ring, counted vmcnt (6 DMA instructions per wave and k-block; the W2 tile's 8 are
@@ -117,10 +172,14 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
       if (ahead >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                                 // k-block t has landed for every wave; everyone has left k-block t-1
+      // k-block t has landed for every wave; everyone has left k-block t-1.  A RAW barrier: __syncthreads() makes hipcc wait vmcnt(0)
+      // while LDS-DMA is in flight, i.e. it drained the two younger k-blocks of the ring at every k-block (round 4: that was the whole
+      // exposed latency of this loop, ~1 us per k-block)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
       if (t + XNS - 1 < nkb) issue(nslot, t + XNS - 1);
-      const char* As = ring + slot * XSTAGE;
-      kblock(As, As + XBM * 128);
+      kblock((uint32_t)(slot * XSTAGE), (uint32_t)(slot * XSTAGE + XBM * 128));
       slot = (slot + 1 == XNS) ? 0 : slot + 1;
       nslot = (nslot + 1 == XNS) ? 0 : nslot + 1;
     }
@@ -146,15 +205,10 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
 
   // ---- epilogue 1: LayerNorm fold + bias + softmax over each 16-column head group (sm_valid columns) -> P (fp16) into the
   // phase-2 A-operand image.  A thread owns the same 8-column chunk in every iteration; its pair lane (nc ^ 1) holds the other half.
-  constexpr int NC = XBN / 8;  // 16
-  const int nc = tid % NC;
   {
-    const float* b1 = p.b1 + (size_t)smp * 128 + nc * 8;
-    const float* l1 = p.lns1 + (size_t)smp * 128 + nc * 8;
-    const f32x4 t0 = *(const f32x4*)b1, t1 = *(const f32x4*)(b1 + 4), u0 = *(const f32x4*)l1, u1 = *(const f32x4*)(l1 + 4);
     float bv[8], lv[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { bv[e] = t0[e]; bv[4 + e] = t1[e]; lv[e] = u0[e]; lv[4 + e] = u1[e]; }
+    for (int e = 0; e < 4; ++e) { bv[e] = e1b0[e]; bv[4 + e] = e1b1[e]; lv[e] = e1l0[e]; lv[4 + e] = e1l1[e]; }
     const int half = (nc & 1) * 8;
     for (int idx = tid; idx < XBM * NC; idx += 256) {
       const int ml = idx / NC;
@@ -188,28 +242,13 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
   __syncthreads();  // P complete (the W2 tile landed before the first phase-1 barrier)
 
   // ---- phase 2: y3 tile = P W2^T over K = 128
-  kblock(ps, w2s);
-  kblock(ps + XBM * 128, w2s + XBN * 128);
+  kblock((uint32_t)(ps - ring), (uint32_t)(w2s - ring));
+  kblock((uint32_t)(ps - ring) + XBM * 128, (uint32_t)(w2s - ring) + XBN * 128);
   __syncthreads();  // everyone has read the staging tile of epilogue 1
   stage_acc();
   __syncthreads();
 
   // ---- epilogue 2: + bias + residual, fp16 store, per-row (sum, sum of squares) of the stored values for the next LayerNorm fold
-  const int n = n0 + nc * 8;
-  const bool col_ok = (n + 8 <= p.C);  // C % 8 == 0
-  float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (col_ok && p.b2) {
-    const f32x4 t0 = *(const f32x4*)(p.b2 + n), t1 = *(const f32x4*)(p.b2 + n + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { bv[e] = t0[e]; bv[4 + e] = t1[e]; }
-  }
-  constexpr int EIT = XBM * NC / 256;  // 4
-  f16x8 rv[EIT];
-#pragma unroll
-  for (int it = 0; it < EIT; ++it) {  // all residual rows up front (clamped rows: unconditional loads)
-    const int mr = min(m0 + (tid + it * 256) / NC, p.S - 1);
-    rv[it] = col_ok ? *(const f16x8*)(p.R + (row0 + mr) * p.ldr + n) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  }
 #pragma unroll
   for (int it = 0; it < EIT; ++it) {
     const int ml = (tid + it * 256) / NC, m = m0 + ml;
@@ -250,7 +289,8 @@ void dtp_xattn_init() { (void)hipFuncSetAttribute((const void*)xattn_kernel, hip
 
 bool dtp_xattn_supported(const XattnParams& p) {
   return p.C >= 64 && (p.C & 63) == 0 && (p.ldx & 7) == 0 && (p.ldy & 7) == 0 && (p.ldr & 7) == 0 && p.S >= 1 && p.N >= 1 && p.sm_valid >= 1 &&
-         p.sm_valid <= 16 && p.st_in && p.st_parts >= 1;
+         p.sm_valid <= 16 && p.st_in && p.st_parts >= 1 &&
+         (size_t)p.S * p.ldx * 2 < ((size_t)1 << 31) && (size_t)(p.C + 128) * 256 < ((size_t)1 << 31);  // 32-bit lane offsets of the DMA
 }
 
 int dtp_launch_xattn(const XattnParams& p, hipStream_t s) {
