@@ -95,6 +95,56 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
   const int kb0 = zid * p.kb_per_split;
   const int nk = min(p.kb_per_split, p.nkb - kb0);
 
+  // ---- epilogue operands of this thread (per-column bias / LayerNorm row sums, the first residual rows): defined here so that the small
+  // tiles can REQUEST them before the first DMA (HOIST; round 4) -- loaded behind the k-loop and the staging barriers they were one
+  // exposed L2 round trip at the end of every latency-bound launch.  Older than every DMA piece, they do not disturb the counted vmcnt.
+  const int fl = p.flags;
+  constexpr int NC = BN / 8;
+  const bool vec_ok = ((p.ldc & 7) == 0) && !(fl & GF_OUT_F32) && (!(fl & GF_RESID) || (p.ldr & 7) == 0);
+  // A thread owns the same 8-column chunk in every iteration (256 % NC == 0): its per-column vectors (bias, lns) are loaded once,
+  // as whole 16-byte loads when the chunk is complete, guarded scalars on the N tail.
+  const int nc = tid % NC, n = n0 + nc * 8;
+  const bool full = (n + 8 <= p.N);
+  float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto load_cols = [&]() {
+    if (full) {
+      if (fl & GF_BIAS) {
+        const f32x4 t0 = *(const f32x4*)(p.bias + n), t1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bv[e] = t0[e]; bv[4 + e] = t1[e]; }
+      }
+      if (fl & GF_LNFOLD) {
+        const f32x4 t0 = *(const f32x4*)(p.lns + n), t1 = *(const f32x4*)(p.lns + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lv[e] = t0[e]; lv[4 + e] = t1[e]; }
+      }
+    } else {
+      for (int e = 0; e < 8 && n + e < p.N; ++e) {
+        if (fl & GF_BIAS) bv[e] = p.bias[n + e];
+        if (fl & GF_LNFOLD) lv[e] = p.lns[n + e];
+      }
+    }
+  };
+  static_assert((BM * NC) % NT == 0 && NT % NC == 0, "every lane runs every iteration and keeps its column chunk");
+  // Residual rows are fetched THREE iterations ahead (a three-register ring, unconditional loads from clamped rows): inside the loop
+  // body a load -> wait -> store sequence per iteration chained one L2 / HBM round trip per row block -- 8-16 of them behind each
+  // other on the 128- and 256-row tiles (the stores to C may alias R for all the compiler knows, so it never hoisted them).
+  constexpr int EIT = BM * NC / NT;
+  const bool pre_r = (fl & GF_RESID) && full && vec_ok;
+  auto load_r = [&](int it) {
+    const int mr = min(m0 + (tid + min(it, EIT - 1) * NT) / NC, p.M - 1);
+    return *(const f16x8*)(p.R + (size_t)mr * p.ldr + n);
+  };
+  f16x8 r0 = {0, 0, 0, 0, 0, 0, 0, 0}, r1 = r0, r2 = r0;
+  constexpr bool HOIST = BM * BN <= 64 * 128;
+  if constexpr (HOIST) {
+    if (p.splits == 1 && !(fl & GF_GEGLU) && tid < NT) {
+      load_cols();
+      if (pre_r) { r0 = load_r(0); r1 = load_r(1); r2 = load_r(2); }
+    }
+  }
+
+
   // ---- DMA source state.  Row r = i*RPR + wave*8 + (lane>>3); LDS slot = lane&7 holds source
   // chunk slot ^ ((r>>1)&7).
   const int lrow = dwave * 8 + (lane >> 3);
@@ -447,7 +497,6 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
     }
   __syncthreads();
 
-  const int fl = p.flags;
   if (fl & GF_GEGLU) {
     // tile columns [0,BN/2) = a, [BN/2,BN) = gate of output features tile_n*BN/2 + ...
     constexpr int HC = BN / 16;  // 8-wide chunks per half
@@ -488,42 +537,10 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
     return;
   }
 
-  constexpr int NC = BN / 8;
-  const bool vec_ok = ((p.ldc & 7) == 0) && !(fl & GF_OUT_F32) && (!(fl & GF_RESID) || (p.ldr & 7) == 0);
-  // A thread owns the same 8-column chunk in every iteration (256 % NC == 0): its per-column vectors (bias, lns) are loaded once,
-  // as whole 16-byte loads when the chunk is complete, guarded scalars on the N tail.
-  const int nc = tid % NC, n = n0 + nc * 8;
-  const bool full = (n + 8 <= p.N);
-  float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (full) {
-    if (fl & GF_BIAS) {
-      const f32x4 t0 = *(const f32x4*)(p.bias + n), t1 = *(const f32x4*)(p.bias + n + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { bv[e] = t0[e]; bv[4 + e] = t1[e]; }
-    }
-    if (fl & GF_LNFOLD) {
-      const f32x4 t0 = *(const f32x4*)(p.lns + n), t1 = *(const f32x4*)(p.lns + n + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { lv[e] = t0[e]; lv[4 + e] = t1[e]; }
-    }
-  } else {
-    for (int e = 0; e < 8 && n + e < p.N; ++e) {
-      if (fl & GF_BIAS) bv[e] = p.bias[n + e];
-      if (fl & GF_LNFOLD) lv[e] = p.lns[n + e];
-    }
+  if constexpr (!HOIST) {
+    load_cols();
+    if (pre_r) { r0 = load_r(0); r1 = load_r(1); r2 = load_r(2); }
   }
-  static_assert((BM * NC) % NT == 0 && NT % NC == 0, "every lane runs every iteration and keeps its column chunk");
-  // Residual rows are fetched THREE iterations ahead (a three-register ring, unconditional loads from clamped rows): inside the loop
-  // body a load -> wait -> store sequence per iteration chained one L2 / HBM round trip per row block -- 8-16 of them behind each
-  // other on the 128- and 256-row tiles (the stores to C may alias R for all the compiler knows, so it never hoisted them).
-  constexpr int EIT = BM * NC / NT;
-  const bool pre_r = (fl & GF_RESID) && full && vec_ok;
-  auto load_r = [&](int it) {
-    const int mr = min(m0 + (tid + min(it, EIT - 1) * NT) / NC, p.M - 1);
-    return *(const f16x8*)(p.R + (size_t)mr * p.ldr + n);
-  };
-  f16x8 r0 = {0, 0, 0, 0, 0, 0, 0, 0}, r1 = r0, r2 = r0;
-  if (pre_r) { r0 = load_r(0); r1 = load_r(1); r2 = load_r(2); }
   int eit = 0;
   for (int idx = tid; idx < BM * NC; idx += NT, ++eit) {
     const f16x8 rcur = r0;
@@ -626,7 +643,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
   for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * W; i < total; i += (long long)gridDim.x * 256 * W) {
     const int m = (int)(i / p.N), n = (int)(i - (long long)m * p.N);
     float x[W];
+    f32x4 bvec = {0.f, 0.f, 0.f, 0.f};
+    f16x4 rvec = {0, 0, 0, 0};
     if constexpr (VEC) {
+      // bias and residual of the item are requested with its first slab, and the last 1-3 slabs together: the item used to chain a
+      // memory round trip per tail slab, one for the bias and one for the residual behind its sums (2-5 slabs since round 4)
+      if (fl & GF_BIAS) bvec = *(const f32x4*)(p.bias + n);
+      if (fl & GF_RESID) rvec = *(const f16x4*)(p.R + (size_t)m * p.ldr + n);
       const float* pp = p.part + i;
       f32x4 a = *(const f32x4*)pp;
       int z = 1;
@@ -635,7 +658,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
         const f32x4 t2 = *(const f32x4*)(pp + (size_t)(z + 2) * total), t3 = *(const f32x4*)(pp + (size_t)(z + 3) * total);
         a += t0; a += t1; a += t2; a += t3;
       }
-      for (; z < p.splits; ++z) a += *(const f32x4*)(pp + (size_t)z * total);
+      const int rem = p.splits - z;  // 0 .. 3, summed in order
+      if (rem == 3) {
+        const f32x4 t0 = *(const f32x4*)(pp + (size_t)z * total), t1 = *(const f32x4*)(pp + (size_t)(z + 1) * total), t2 = *(const f32x4*)(pp + (size_t)(z + 2) * total);
+        a += t0; a += t1; a += t2;
+      } else if (rem == 2) {
+        const f32x4 t0 = *(const f32x4*)(pp + (size_t)z * total), t1 = *(const f32x4*)(pp + (size_t)(z + 1) * total);
+        a += t0; a += t1;
+      } else if (rem == 1) {
+        a += *(const f32x4*)(pp + (size_t)z * total);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) x[e] = a[e];
     } else {
@@ -644,18 +676,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     }
 #pragma unroll
     for (int e = 0; e < W; ++e) {
-      if (fl & GF_BIAS) x[e] += p.bias[n + e];
+      if constexpr (VEC) { x[e] += bvec[e]; }
+      else if (fl & GF_BIAS) x[e] += p.bias[n + e];
       if (fl & GF_BIAS_M) x[e] += p.bias[m];
       if (fl & GF_GELU) x[e] = gelu_erf(x[e]);
       if (fl & GF_QUICKGELU) x[e] = x[e] / (1.0f + __expf(-1.702f * x[e]));
       if (fl & GF_SILU) x[e] = x[e] / (1.0f + __expf(-x[e]));
     }
     if constexpr (VEC) {
-      if (fl & GF_RESID) {
-        const f16x4 r = *(const f16x4*)(p.R + (size_t)m * p.ldr + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] += (float)r[e];
-      }
+      for (int e = 0; e < 4; ++e) x[e] += (float)rvec[e];
       const f16x4 o = {(f16)x[0], (f16)x[1], (f16)x[2], (f16)x[3]};
       *(f16x4*)((f16*)p.C + (size_t)m * p.ldc + n) = o;
     } else {
@@ -873,7 +903,7 @@ int dtp_launch_splitk_reduce(const GemmParams& p, hipStream_t s) {
   }
   long long total = (long long)p.M * p.N;
   const bool vec = (p.N & 3) == 0 && !(p.flags & GF_OUT_F32) && (p.ldc & 3) == 0 && (!(p.flags & GF_RESID) || (p.ldr & 3) == 0) &&
-                   (((uintptr_t)p.C | (uintptr_t)p.R) & 7) == 0;
+                   (((uintptr_t)p.C | (uintptr_t)p.R) & 7) == 0 && (!(p.flags & GF_BIAS) || ((uintptr_t)p.bias & 15) == 0);
   int blocks = (int)((total / (vec ? 4 : 1) + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;

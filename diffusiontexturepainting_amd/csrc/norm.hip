@@ -421,6 +421,28 @@ __global__ __launch_bounds__(256) void gn_fold_weights_kernel(const f16* __restr
   __shared__ float ad[3][2048];  // a_b[c], beta[c], mean of c's group
   __shared__ float red[256];
   const int b = blockIdx.y, tid = threadIdx.x;
+  // Everything that does not depend on the statistics is requested first (round 4: the kernel used to chain partial sums -> gamma /
+  // beta -> weight rows -> bias, one memory round trip each): the affine parameters of this thread's channels, the weight chunks of
+  // the first two row passes and their bias entries.  Clamped indices: the loads are unconditional.
+  constexpr int MAXCK = 8;  // C <= 2048
+  float gmv[MAXCK], btv[MAXCK];
+#pragma unroll
+  for (int k = 0; k < MAXCK; ++k) {
+    const int c = min(tid + k * 256, C - 1);
+    gmv[k] = gamma[c];
+    btv[k] = beta[c];
+  }
+  const int nch = C >> 3, rpp = 256 / nch;  // 8-channel chunks per row; rows per pass
+  const int cc = tid % nch, rr = tid / nch;
+  constexpr int PREP = 2;
+  f16x8 pw[PREP];
+  float pbias[PREP];
+#pragma unroll
+  for (int k = 0; k < PREP; ++k) {
+    const int n = min(blockIdx.x * 8 + k * rpp + rr, Nout - 1);
+    pw[k] = *(const f16x8*)(W + (size_t)n * ldw + cc * 8);
+    pbias[k] = bias ? bias[n] : 0.f;
+  }
   {
     const int g = tid >> 3, j = tid & 7;
     float s = 0.f, q = 0.f;
@@ -435,23 +457,28 @@ __global__ __launch_bounds__(256) void gn_fold_weights_kernel(const f16* __restr
     }
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    const int g = c / cpg;
-    const float a = gamma[c] * st[g * 2 + 1];
-    ad[0][c] = a;
-    ad[1][c] = beta[c];
-    ad[2][c] = st[g * 2];
+#pragma unroll
+  for (int k = 0; k < MAXCK; ++k) {
+    const int c = tid + k * 256;
+    if (c < C) {
+      const int g = c / cpg;
+      ad[0][c] = gmv[k] * st[g * 2 + 1];
+      ad[1][c] = btv[k];
+      ad[2][c] = st[g * 2];
+    }
   }
   __syncthreads();
-  const int nch = C >> 3, rpp = 256 / nch;  // 8-channel chunks per row; rows per pass
-  const int cc = tid % nch, rr = tid / nch;
   f16* Wb = Wout + (size_t)b * w_bs;
-  for (int r0 = 0; r0 < 8; r0 += rpp) {
+  int pass = 0;
+  for (int r0 = 0; r0 < 8; r0 += rpp, ++pass) {
     const int n = blockIdx.x * 8 + r0 + rr;
     const bool act = rr < rpp && r0 + rr < 8 && n < Nout;
-    float acc = 0.f;
+    float acc = 0.f, bn = 0.f;
     if (act) {
-      const f16x8 w = *(const f16x8*)(W + (size_t)n * ldw + cc * 8);
+      f16x8 w;
+      if (pass == 0) { w = pw[0]; bn = pbias[0]; }
+      else if (pass == 1) { w = pw[1]; bn = pbias[1]; }
+      else { w = *(const f16x8*)(W + (size_t)n * ldw + cc * 8); bn = bias ? bias[n] : 0.f; }
       f16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -468,7 +495,7 @@ __global__ __launch_bounds__(256) void gn_fold_weights_kernel(const f16* __restr
     if (act && cc == 0) {
       float t = 0.f;
       for (int k = 0; k < nch; ++k) t += red[rr * nch + k];
-      bias_out[(size_t)b * bias_bs + n] = (bias ? bias[n] : 0.f) + t;
+      bias_out[(size_t)b * bias_bs + n] = bn + t;
     }
     __syncthreads();
   }
