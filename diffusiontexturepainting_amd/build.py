@@ -17,7 +17,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 
-EXTRA = {"attention.hip": ["-ffast-math"]}  # softmax inner loop: raw v_exp_f32 / v_max3, finite sentinels only
+EXTRA = {"attention.hip": ["-ffast-math"], "attn_dma.hip": ["-ffast-math"]}  # softmax inner loop: raw v_exp_f32 / v_max3, finite sentinels only
 
 
 def _sources():
@@ -61,6 +61,10 @@ def build(verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    # every symbol must resolve HERE, not on the GPU box (an anonymous-namespace kernel whose host stub the compiler dropped links fine
+    # and only fails at dlopen: round 5, attn_dma.hip)
+    import ctypes
+    ctypes.CDLL(LIB)
     if verbose:
         print(f"[dtp.build] {LIB} ({os.path.getsize(LIB) // 1024} KiB) from {len(objs)} objects")
     return LIB

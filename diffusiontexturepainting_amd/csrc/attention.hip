@@ -372,6 +372,9 @@ int dtp_launch_attention(const AttnParams& pin, hipStream_t s) {
     dtp_set_error("attention: D=%d ldq=%d ldk=%d ldv=%d ldo=%d unsupported", p.D, p.ldq, p.ldk, p.ldv, p.ldo);
     return DTP_ERR_ARG;
   }
+  // round 5: the long full-tile launches (UNet levels 0 / 1) run on the LDS-DMA kernel (attn_dma.hip); $DTP_ATTN_DMA=0 keeps them here (A/B)
+  static const int dma_env = [] { const char* e = getenv("DTP_ATTN_DMA"); return e ? atoi(e) : 1; }();
+  if (dma_env && dtp_attention_dma_supported(p)) return dtp_launch_attention_dma(p, s);
   dim3 grid((p.Sq + 127) / 128, p.H, p.B), block(256);
   static const int cus = [] {
     int dev = 0;

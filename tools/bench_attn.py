@@ -34,11 +34,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         child()
     else:
-        libs = [("shipped", None), ("shipped DTP_ATTN_NW8=0", "NW8=0"), ("shipped DTP_ATTN_NW8=1", "NW8=1")] + [(os.path.basename(p), p) for p in sorted(glob.glob(os.path.join(ROOT, "tools/ab/libdtp_attn_*.so")))]
+        libs = [("shipped", None), ("shipped DTP_ATTN_DMA=0", "DMA=0")] + [(os.path.basename(p), p) for p in sorted(glob.glob(os.path.join(ROOT, "tools/ab/libdtp_attn_*.so")))]
         for name, path in libs:
             env = dict(os.environ)
-            if path and path.startswith("NW8="):
-                env["DTP_ATTN_NW8"] = path[4:]
+            if path and path.startswith("DMA="):
+                env["DTP_ATTN_DMA"] = path[4:]
             elif path:
                 env["DTP_LIB"] = path
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True)
