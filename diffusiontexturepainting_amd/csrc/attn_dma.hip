@@ -25,6 +25,17 @@
 #include <type_traits>
 #include <utility>
 
+#ifdef DTP_AD_TRACE  // diagnostic build (tools/attn_variants.sh): s_memtime stamps of one wave's key loop, read back by tools/attn_trace.py
+__device__ unsigned long long dtp_ad_trace_buf[16384];
+extern "C" int dtp_ad_trace_read(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dtp_ad_trace_buf), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+#define DTP_AD_STAMP(slot)                                                                                         \
+  if (trace_me && t < 40) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dtp_ad_trace_buf[trace_base + t * 8 + (slot)] = __builtin_readcyclecounter(); }
+#else
+#define DTP_AD_STAMP(slot)
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -188,65 +199,37 @@ __global__ __launch_bounds__(256, D <= 40 ? 3 : 2) void attn_dma_kernel(const At
 #pragma unroll
   for (int r = 0; r < 16; ++r) mvec[r] = 0.f;
   float lsum[4] = {0.f, 0.f, 0.f, 0.f};
-  constexpr float THR = 6.0f;
-  float thr = -3.0e38f;  // the first tile moves every row's reference onto its maximum; afterwards only scores 2^THR above it do
+  constexpr float THR = 6.0f;  // a reference moves when a score exceeds it by 2^THR (fp16 P holds 2^16)
 
-  int stage = 0, istage = NS - 1;  // ring slot of tile t / of tile t + NS - 1
-#pragma clang loop unroll(disable)  // (also keeps hipcc from peeling the first tile: twice the code for one iteration)
-  for (int t = 0; t < T; ++t) {
-    // tile t has landed (this wave's pieces: counted vmcnt -- the younger tiles stay in flight), for every wave (barrier); and every
-    // wave has left tile t - 1, whose slot the next DMA overwrites
-    if (t + NS - 2 < T) {  // steady state: NS - 2 younger tiles of this wave's pieces stay in flight
-      if constexpr (NP % 4 == 0) wait_vm<(NS - 2) * PW>();
-      else if (wave < NP % 4) wait_vm<(NS - 2) * PW>();
-      else wait_vm<(NS - 2) * (PW - 1)>();
-    } else {
-      wait_vm<0>();  // the last NS - 2 tiles: nothing younger worth keeping in flight
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (t + NS - 1 < T) DTP_AD_ISSUE(t + NS - 1, istage);
-    const uint32_t ka = kaddr0 + stage * STAGE, va = vaddr0 + stage * STAGE;
-
-    // ---- fragment requests: K (consumption order), then the V^T fragments of key block 0 (every address = per-lane base + immediate)
-    f16x8 kf[KS][2];
+  // ---- the key loop, software-pipelined over 32-key HALF tiles inside each wave: while the matrix pipe multiplies the scores of half
+  // h + 1 (KS MFMAs) and then P V of half h (2 DB MFMAs), the VALU exponentiates / packs half h and takes the row maximum of half h + 1.
+  // (Round 5, first version: whole 64-key tiles one after the other -- scores, softmax, P V -- relied on the three co-resident waves
+  // of a SIMD to overlap the pipes; PMC showed they do not: MFMA 448 + VALU ~580 + waits = 1190 cycles per tile and wave.)  Two score
+  // accumulators (32 registers, as before) alternate roles; the reference check runs per half.
+  constexpr int WSTEP = (ST == 4 ? 2 : 8) * RS;  // a V^T fragment's second read: keys 8 further on
+  constexpr int NVH = 4 * DB;                     // V reads per half tile
+  auto qk_plain = [&](f32x16& nxt, uint32_t ka_n) {  // the very first half: nothing to overlap with
+    f16x8 kf[KS];
+    static_for<KS>([&](auto ksc) { constexpr int ks = decltype(ksc)::value; kf[ks] = ld_b128<ks * 32>(ka_n); });
     static_for<KS>([&](auto ksc) {
       constexpr int ks = decltype(ksc)::value;
-      kf[ks][0] = ld_b128<ks * 32>(ka);
-      kf[ks][1] = ld_b128<32 * RS + ks * 32>(ka);
+      wait_lgkm<KS - 1 - ks>(kf[ks]);
+      nxt = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], ks == 0 ? mvec : nxt, 0, 0, 0);
     });
-    // V^T fragment (kb, s, db): two transpose reads (k-slots 0-3 / 4-7 of the lane's half; the second read's keys are 8 further on)
-    constexpr int WSTEP = (ST == 4 ? 2 : 8) * RS;
-    f16x4 vf[2][2][DB][2];
-    auto vreads = [&](auto kbc) {
-      constexpr int kb = decltype(kbc)::value;
-      static_for<2 * DB>([&](auto i) {
-        constexpr int s = decltype(i)::value / DB, db = decltype(i)::value % DB, off = (32 * kb + 16 * s) * RS + db * 64;
-        vf[kb][s][db][0] = ld_tr<off>(va);
-        vf[kb][s][db][1] = ld_tr<off + WSTEP>(va);
-      });
-    };
-    constexpr int NVR = 4 * DB, NK = 2 * KS;        // V reads per key block, K reads
-    constexpr bool V0_EARLY = (NK + NVR) <= 15;     // lgkmcnt counts to 15
-    if constexpr (V0_EARLY) vreads(IC<0>{});
-
-    // ---- S^T = K Q'^T - m_ref  (two 32-key blocks, their MFMA chains interleaved; each MFMA waits for exactly its fragment)
-    f32x16 sacc[2];
-    static_for<NK>([&](auto ic) {
-      constexpr int i = decltype(ic)::value, ks = i / 2, kb = i % 2;
-      wait_lgkm<NK - 1 - i + (V0_EARLY ? NVR : 0)>(kf[ks][kb]);
-      sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][kb], qf[ks], ks == 0 ? mvec : sacc[kb], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);  // (left alone, hipcc gathers all the waits in front of the first MFMA)
-    });
-    if constexpr (!V0_EARLY) vreads(IC<0>{});
-    if constexpr (DB == 2) vreads(IC<1>{});  // d = 40: 16 requests, the older eight long landed
-
-    // ---- online softmax: this lane holds 32 of its query's 64 scores (the other half-wave the other 32)
-    float mloc = fmaxf(sacc[0][0], sacc[1][0]);
+  };
+  // row maximum of a half tile's 16 + 16 scores; moves the reference of the rows that need it (rare after the first tile)
+  auto row_max = [&](const f32x16& nxt) {
+    float mloc = fmaxf(nxt[0], nxt[1]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, sacc[0][r]), sacc[1][r]);
+    for (int r = 2; r < 16; r += 2) mloc = fmaxf(fmaxf(mloc, nxt[r]), nxt[r + 1]);
+    return mloc;
+  };
+  auto check = [&](f32x16& nxt, float mloc, float thr) {  // mloc: this lane's maximum over nxt
+#ifdef DTP_AD_NO_CHECK
+    if (thr > 0.f) { asm volatile("" ::"v"(mloc)); return; }
+#endif
     { float lo, hi; both_halves(mloc, lo, hi); mloc = fmaxf(lo, hi); }
-    if (__any(mloc > thr)) {  // move the reference of the rows that need it (all rows on the first tile)
+    if (__any(mloc > thr)) {
       const float delta = (mloc > thr) ? mloc : 0.f;
       const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
@@ -256,39 +239,166 @@ __global__ __launch_bounds__(256, D <= 40 ? 3 : 2) void attn_dma_kernel(const At
 #pragma unroll
       for (int i = 0; i < 4; ++i) lsum[i] *= alpha;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[kb][r] -= delta;
+      for (int r = 0; r < 16; ++r) nxt[r] -= delta;
 #pragma unroll
       for (int r = 0; r < 16; ++r) mvec[r] -= delta;
     }
-    thr = THR;
-    f16x8 pf[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 w;
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          const float p0 = __builtin_amdgcn_exp2f(sacc[kb][8 * s + e]), p1 = __builtin_amdgcn_exp2f(sacc[kb][8 * s + e + 1]);
-          lsum[(e >> 1) & 3] += p0 + p1;
-          w[e >> 1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(p0, p1));
-        }
-        pf[kb][s] = __builtin_bit_cast(f16x8, w);
-      }
-    if constexpr (DB != 2) vreads(IC<1>{});
-
-    // ---- O^T += V^T P^T: all 8 DB reads are requested, fragment j = (kb, s, db) needs the first 2 (j + 1) of them
-    static_for<4 * DB>([&](auto jc) {
-      constexpr int j = decltype(jc)::value, kb = j / (2 * DB), s = (j / DB) % 2, db = j % DB;
-      constexpr int left = 8 * DB - 2 * (j + 1);
-      wait_lgkm<(left < 15 ? left : 15)>(vf[kb][s][db][0], vf[kb][s][db][1]);
-      oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-          __builtin_shufflevector(vf[kb][s][db][0], vf[kb][s][db][1], 0, 1, 2, 3, 4, 5, 6, 7), pf[kb][s], oacc[db], 0, 0, 0);
+  };
+  // one half tile: cur = its scores (already re-based), nxt <- the scores of the next half (K fragments at ka_n), V^T fragments at va_c
+  auto half_step = [&](f32x16& cur, f32x16& nxt, uint32_t ka_n, uint32_t va_c) -> float {
+    f16x8 kf[KS];
+    f16x4 vf[2][DB][2];
+#ifndef DTP_AD_NO_KREAD  // (diagnostic builds only: tools/attn_variants.sh)
+    static_for<KS>([&](auto ksc) { constexpr int ks = decltype(ksc)::value; kf[ks] = ld_b128<ks * 32>(ka_n); });
+#else
+    static_for<KS>([&](auto ksc) { constexpr int ks = decltype(ksc)::value; kf[ks] = qf[ks]; });
+#endif
+    static_for<2 * DB>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, s = i / DB, db = i % DB, off = 16 * s * RS + db * 64;
+#ifndef DTP_AD_NO_VREAD
+      vf[s][db][0] = ld_tr<off>(va_c);
+      vf[s][db][1] = ld_tr<off + WSTEP>(va_c);
+#else
+      vf[s][db][0] = f16x4{qf[0][0], qf[0][1], qf[0][2], qf[0][3]};
+      vf[s][db][1] = f16x4{qf[0][4], qf[0][5], qf[0][6], qf[0][7]};
+#endif
     });
-    stage = (stage + 1 == NS) ? 0 : stage + 1;
+    // The instruction order below is pinned group by group (sched_barrier): left alone, hipcc gathers every wait in front of the first
+    // MFMA.  VALU work that needs no fragment comes first (it covers the LDS latency of the requests above), then every MFMA is followed
+    // by its share of the exponentials / packs / sums: the matrix pipe (32 cycles per MFMA) and the VALU run side by side in ONE wave.
+    float pe[16];
+    f16x8 pf[2];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto expo = [&](int lo, int hi) {
+#pragma unroll
+      for (int i = lo; i < hi; ++i) {
+#ifndef DTP_AD_NO_EXP
+        pe[i] = __builtin_amdgcn_exp2f(cur[i]);
+#else
+        pe[i] = cur[i] * 1e-3f;
+#endif
+      }
+    };
+    auto pack = [&](int sidx) {
+      u32x4 w;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) w[e >> 1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(pe[8 * sidx + e], pe[8 * sidx + e + 1]));
+      pf[sidx] = __builtin_bit_cast(f16x8, w);
+    };
+    auto qk = [&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value, left = KS - 1 - ks + NVH;
+      wait_lgkm<(left < 15 ? left : 15)>(kf[ks]);
+#ifndef DTP_AD_NO_MFMA
+      nxt = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], ks == 0 ? mvec : nxt, 0, 0, 0);
+#else
+      if (ks == 0) nxt = mvec;
+      { f32x16& sa = nxt; f16x8 &kr = kf[ks], &qr = qf[ks]; asm volatile("" : "+v"(sa) : "v"(kr), "v"(qr)); }
+#endif
+    };
+    auto pv = [&](auto jc) {  // O^T += V^T P^T: fragment j = (s, db) needs the first 2 (j + 1) of the NVH reads
+      constexpr int j = decltype(jc)::value, sx = j / DB, db = j % DB, left = NVH - 2 * (j + 1);
+      wait_lgkm<left>(vf[sx][db][0], vf[sx][db][1]);
+#ifndef DTP_AD_NO_MFMA
+      oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+          __builtin_shufflevector(vf[sx][db][0], vf[sx][db][1], 0, 1, 2, 3, 4, 5, 6, 7), pf[sx], oacc[db], 0, 0, 0);
+#else
+      { f32x16& oa = oacc[db]; f16x4 &v0 = vf[sx][db][0], &v1 = vf[sx][db][1]; f16x8& pr = pf[sx]; asm volatile("" : "+v"(oa) : "v"(v0), "v"(v1), "v"(pr)); }
+#endif
+    };
+    __builtin_amdgcn_sched_barrier(0);  // (the requests above stay in front of the exponentials that cover their latency)
+    expo(0, 8); pack(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // scores of the next half: a chain of KS MFMAs on one accumulator, the second half of the exponentials between them
+    static_for<KS>([&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      qk(ksc);
+      constexpr int e0 = 8 + (8 * ks) / KS, e1 = 8 + (8 * (ks + 1)) / KS;
+      expo(e0, e1);
+      if (ks == KS - 1) pack(1);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // P V with the row sums and the next half's row maximum between the MFMAs
+    float mloc = fmaxf(nxt[0], nxt[1]);
+    static_for<2 * DB>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      pv(jc);
+      constexpr int a0 = (16 * j) / (2 * DB), a1 = (16 * (j + 1)) / (2 * DB);
+#pragma unroll
+      for (int i = a0; i < a1; ++i) {
+#ifndef DTP_AD_NO_LSUM
+        lsum[i & 3] += pe[i];
+#else
+        asm volatile("" ::"v"(pe[i]));
+#endif
+      }
+      constexpr int m0 = 1 + (7 * j) / (2 * DB), m1 = 1 + (7 * (j + 1)) / (2 * DB);
+#pragma unroll
+      for (int i = m0; i < m1; ++i) {
+#ifndef DTP_AD_NO_MAX
+        mloc = fmaxf(fmaxf(mloc, nxt[2 * i]), nxt[2 * i + 1]);
+#endif
+      }
+      asm volatile("" : "+v"(mloc));  // (keeps the chain here, under the MFMAs: hipcc otherwise sinks it behind the caller's branch)
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    return mloc;
+  };
+
+  // prologue: tile 0 has landed (for every wave); scores of its first half
+  if (T >= NS - 1) {
+    if constexpr (NP % 4 == 0) wait_vm<(NS - 2) * PW>();
+    else if (wave < NP % 4) wait_vm<(NS - 2) * PW>();
+    else wait_vm<(NS - 2) * (PW - 1)>();
+  } else {
+    wait_vm<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  f32x16 sA, sB;
+  qk_plain(sA, kaddr0);
+  check(sA, row_max(sA), -3.0e38f);  // every row's reference moves onto its first maximum
+
+  int stage = 0, nstage = 1, istage = NS - 1;  // ring slots of tile t, t + 1 and t + NS - 1
+#ifdef DTP_AD_TRACE
+  const bool trace_me = (lane == 0) && (blockIdx.x == 0 || blockIdx.x == 300 || blockIdx.x == 700);
+  const int trace_base = ((blockIdx.x == 0 ? 0 : blockIdx.x == 300 ? 1 : 2) * 4 + wave) * 512;
+#endif
+#pragma clang loop unroll(disable)  // (also keeps hipcc from peeling an iteration: twice the code)
+  for (int t = 0; t < T; ++t) {
+    const uint32_t so = stage * STAGE;
+    DTP_AD_STAMP(0)
+    const float mB = half_step(sA, sB, kaddr0 + so + 32 * RS, vaddr0 + so);
+    DTP_AD_STAMP(1)
+    check(sB, mB, THR);
+    DTP_AD_STAMP(2)
+    // tile t + 1 has landed (this wave's pieces: counted vmcnt, the younger tiles stay in flight), for every wave (barrier); and every wave
+    // has left tile t - 1, whose slot the next DMA overwrites
+#ifndef DTP_AD_NO_VMWAIT
+    if (t + NS - 2 < T) {
+      if constexpr (NP % 4 == 0) wait_vm<(NS - 3) * PW>();
+      else if (wave < NP % 4) wait_vm<(NS - 3) * PW>();
+      else wait_vm<(NS - 3) * (PW - 1)>();
+    } else {
+      wait_vm<0>();
+    }
+#endif
+    DTP_AD_STAMP(3)
+#ifndef DTP_AD_NO_BARRIER
+    __builtin_amdgcn_s_barrier();
+#endif
+    asm volatile("" ::: "memory");
+    DTP_AD_STAMP(4)
+#ifndef DTP_AD_NO_DMA
+    if (t + NS - 1 < T) DTP_AD_ISSUE(t + NS - 1, istage);
+#endif
+    DTP_AD_STAMP(5)
+    // (the last tile's second half multiplies whatever the next slot holds -- finite -- into scores nobody uses, without a reference check)
+    const float mA = half_step(sB, sA, kaddr0 + nstage * STAGE, vaddr0 + so + 32 * RS);
+    DTP_AD_STAMP(6)
+    if (t + 1 < T) check(sA, mA, THR);
+    DTP_AD_STAMP(7)
+    stage = nstage;
+    nstage = (nstage + 1 == NS) ? 0 : nstage + 1;
     istage = (istage + 1 == NS) ? 0 : istage + 1;
   }
 
