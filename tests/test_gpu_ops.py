@@ -678,11 +678,12 @@ def test_attention_eight_wave_workgroups_on_a_batched_launch(ops):
 
 
 @pytest.mark.parametrize("b,sq,skv,heads,d", [(3, 4096, 4096, 8, 40), (3, 1024, 1024, 8, 80), (1, 200, 256, 8, 40), (2, 40, 128, 4, 80),
-                                              (1, 1024, 1024, 5, 40), (2, 300, 640, 8, 80), (24, 256, 256, 8, 40)])
+                                              (1, 1024, 1024, 5, 40), (2, 300, 640, 8, 80), (24, 256, 256, 8, 40), (130, 500, 512, 8, 40)])
 def test_attention_dma_kernel(ops, b, sq, skv, heads, d):
     """attn_dma_kernel (round 5: K / V tiles by LDS-DMA, V^T fragments by ds_read_b64_tr_b16, the softmax shift in the MFMA's C operand):
     the UNet's level-0 / level-1 launches at batch 1, ragged query blocks, Sq != Skv, a (batch x heads) count that is not a multiple
-    of 8 (the plain block -> (head, query block) map), short sequences (2 tiles: shorter than the DMA ring), many small problems."""
+    of 8 (the plain block -> (head, query block) map), short sequences (2 tiles: shorter than the DMA ring), many small problems, and a
+    launch with >= 8 x CUs 256-query blocks (130 samples x 8 heads x 2: the eight-wave build, one K / V tile staged for 256 queries)."""
     c = heads * d
     q, k, v = rnd(b, sq, c, seed=260), rnd(b, skv, c, seed=261), rnd(b, skv, c, seed=262)
     ref = _attn_ref(q, k, v, heads)

@@ -5,7 +5,7 @@ import glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SHAPES = [(3, 4096, 320, 8), (24, 4096, 320, 8), (3, 1024, 640, 8), (3, 256, 1280, 8), (3, 64, 1280, 8)]
+SHAPES = [(3, 4096, 320, 8), (24, 4096, 320, 8), (3, 1024, 640, 8), (24, 1024, 640, 8), (3, 1024, 320, 8), (3, 256, 1280, 8), (3, 64, 1280, 8)]
 
 
 def child():
@@ -34,11 +34,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         child()
     else:
-        libs = [("shipped", None), ("shipped DTP_ATTN_DMA=0", "DMA=0")] + [(os.path.basename(p), p) for p in sorted(glob.glob(os.path.join(ROOT, "tools/ab/libdtp_attn_*.so")))]
+        libs = [("shipped", None), ("shipped DTP_ATTN_DMA=0", "DMA=0"), ("shipped DTP_ATTN_NW8=0", "NW8=0")] + [(os.path.basename(p), p) for p in sorted(glob.glob(os.path.join(ROOT, "tools/ab/libdtp_attn_*.so")))]
         for name, path in libs:
             env = dict(os.environ)
             if path and path.startswith("DMA="):
                 env["DTP_ATTN_DMA"] = path[4:]
+            elif path and path.startswith("NW8="):
+                env["DTP_ATTN_NW8"] = path[4:]
             elif path:
                 env["DTP_LIB"] = path
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True)
