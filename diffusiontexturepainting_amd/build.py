@@ -15,6 +15,10 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libdtp.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+# DTP_EXPERIMENTAL=1: also build the measured-and-switched-off experiments (gemmws_kernel = tile 55, GroupNorm on the halo conv's staged
+# patch, the two-pass small-map GroupNorm, the attention start skew); their tests (marker `experimental`) skip on the default build
+if os.environ.get("DTP_EXPERIMENTAL", "0") not in ("", "0"):
+    FLAGS.append("-DDTP_EXPERIMENTAL")
 
 
 EXTRA = {"attention.hip": ["-ffast-math"], "attn_dma.hip": ["-ffast-math"]}  # softmax inner loop: raw v_exp_f32 / v_max3, finite sentinels only

@@ -186,9 +186,11 @@ __global__ __launch_bounds__(64 * NW, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 
 
   // experiment ($DTP_ATTN_SKEW=n): co-resident workgroups start in lockstep and run equal-length phases, so the waves of a SIMD ask
   // for the matrix pipe (and then for the VALU) all at once; delaying every other workgroup by n * 64 cycles de-phases them
+#ifdef DTP_EXPERIMENTAL
   if (p.skew > 0 && (qblk & 1)) {
     for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(1);
   }
+#endif
   const char* const kfrag0 = Kl + lq * KROW + hf * 16;  // this lane's K / V^T fragment rows (buffer 0)
   const char* const vfrag0 = Vl + lq * VROW + hf * 16;
   prefetch(0);

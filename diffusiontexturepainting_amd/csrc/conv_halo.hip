@@ -465,9 +465,11 @@ int launch_halo(const GemmParams& pin, hipStream_t s) {
   const bool xs = !xcd_off && dtp_xcd_split_ok(blocks, p.splits);
   if (xs) p.flags |= GF_XCDSPLIT;
   const dim3 grid = xs ? dim3(blocks * p.splits, 1, 1) : dim3(blocks, 1, p.splits);
+#ifdef DTP_EXPERIMENTAL  // (GroupNorm on the staged patch measured +4.9 ms per stamp, DESIGN.md 3.6: an experiment, not in the product library)
   if (p.flags & GF_GNAPPLY)
     hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, true>), grid, dim3(256), lds + p.Cin * 8 + 256, s, p);
   else
+#endif
     hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, false>), grid, dim3(256), lds, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
@@ -478,7 +480,9 @@ template <int TH, int TW, int BN>
 static void set_halo_attr() {
   constexpr int lds = halo_lds<TH, TW, BN>();
   (void)hipFuncSetAttribute((const void*)conv_halo_kernel<TH, TW, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#ifdef DTP_EXPERIMENTAL
   (void)hipFuncSetAttribute((const void*)conv_halo_kernel<TH, TW, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + GN_MAX_CIN * 8 + 256);
+#endif
 }
 
 void dtp_conv_halo_init() {
@@ -493,6 +497,9 @@ void dtp_conv_halo_init() {
 // variant: 0 = 8x16 x 64, 1 = 8x16 x 128, 2 = 8x8 x 64, 3 = 8x8 x 128.  p.W must be the channel-block-major packing
 // ([cb][tap][64] then the fused-shortcut columns); p.kb_per_split / p.splits count 64-wide k-blocks like gemm_kernel.
 bool dtp_conv_halo_supported(const GemmParams& p) {
+#ifndef DTP_EXPERIMENTAL
+  if (p.flags & GF_GNAPPLY) return false;
+#endif
   if ((p.flags & GF_GNAPPLY) && (!p.gn_part || !p.gn_gamma || !p.gn_beta || p.Cin > GN_MAX_CIN || p.gn_cpg < 1 || (p.Cin % p.gn_cpg) || p.Cin / p.gn_cpg > 32 ||
                                  p.gn_nchunk < 1))
     return false;

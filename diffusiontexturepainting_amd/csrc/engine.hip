@@ -396,8 +396,29 @@ bool Builder::claim_stats(const T& x, float** partials, int* nchunk) {
     return false;
   GemmParams gp = lg.p;
   const int chunks = 2 * (gp.Ho / 8) * (gp.Wo / 16);
+  // every block of the consumer re-reads its image's whole partials table (chunks x 32 x 8 bytes): beyond ~1k chunks (the VAE's 512^2 and
+  // 256^2 maps: 1 MB per image) that is more traffic than the statistics pass it replaces (round-4 advisor) -- those keep the pass
+  if (chunks > 1024) return false;
+  // The conv's input (and residual / shortcut operand) may already be back in the pool -- gn_conv3 releases it before its consumer is
+  // built -- and the pool would happily hand that very block out for the partials, which the re-pushed conv WRITES while other
+  // workgroups still read the operand (round-4 advisor: a latent aliasing race).  Blocks that overlap an operand are set aside.
+  const size_t need = (size_t)x.B * chunks * 32 * 2 * sizeof(float);
   void* pp = nullptr;
-  if (ctx_pool_get(c, (size_t)x.B * chunks * 32 * 2 * sizeof(float), &pp) != DTP_OK) return false;
+  std::vector<void*> aside;
+  auto overlaps = [&](const void* q, size_t bytes) {
+    const char* a = (const char*)q;
+    auto hit = [&](const void* o, size_t ob) { return o && a < (const char*)o + ob && (const char*)o < a + bytes; };
+    const size_t in_bytes = (size_t)x.B * gp.Hi * gp.Wi * gp.lda * sizeof(f16);
+    return hit(gp.A, in_bytes) || hit(gp.A2, (size_t)gp.M * gp.lda2 * sizeof(f16)) || hit(gp.R, (size_t)gp.M * gp.ldr * sizeof(f16));
+  };
+  bool ok = false;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    if (ctx_pool_get(c, need, &pp) != DTP_OK) break;
+    if (!overlaps(pp, need)) { ok = true; break; }
+    aside.push_back(pp);
+  }
+  for (void* q : aside) ctx_pool_put(c, q);
+  if (!ok) return false;
   gp.flags |= GF_GNSTATS;
   gp.st_out = (float*)pp;
   gp.gn_cpg = x.C / 32;
@@ -801,7 +822,12 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
 }
 
 float* fp8_new_linear_scale(Ctx* c, int* slot1) {
-  if (c->fp8_nslots + 1 > DTP_FP8_SLOTS) { *slot1 = 0; return nullptr; }
+  if (c->fp8_nslots + 1 > DTP_FP8_SLOTS) {  // (round-4 advisor: this fallback to the default scale used to be silent)
+    static bool warned = false;
+    if (!warned) { fprintf(stderr, "[dtp] fp8: the %d calibration slots are used up -- further fp8 operands keep the default activation scale\n", DTP_FP8_SLOTS); warned = true; }
+    *slot1 = 0;
+    return nullptr;
+  }
   c->fp8_scales.push_back(1.0f);
   Fp8Cal r;
   r.kind = 0; r.slot0 = c->fp8_nslots; r.s0 = &c->fp8_scales.back();
@@ -1113,7 +1139,9 @@ int dtp_create(int device, int resolution, int max_batch, dtp_ctx** out) {
   tune_cache_load(c);
   if (const char* e = getenv("DTP_NO_FUSE_REDUCE_GN")) c->fuse_reduce_gn = !(e[0] && e[0] != '0');
   if (const char* e = getenv("DTP_NO_DEDUPE")) c->dedupe_prefix = !(e[0] && e[0] != '0');
+#ifdef DTP_EXPERIMENTAL
   if (const char* e = getenv("DTP_GN_CONV")) c->fuse_gn_conv = (e[0] && e[0] != '0');
+#endif
   if (const char* e = getenv("DTP_NO_XATTN")) c->fuse_xattn = !(e[0] && e[0] != '0');
   if (const char* e = getenv("DTP_NO_FOLD_GN")) c->fold_gn_linear = !(e[0] && e[0] != '0');
   *out = (dtp_ctx*)c;

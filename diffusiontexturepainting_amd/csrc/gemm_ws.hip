@@ -24,6 +24,7 @@
 
 #include "common.h"
 
+#ifdef DTP_EXPERIMENTAL  // round 5: an opt-in experiment that ties the tiled kernels is not part of the product library
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -378,3 +379,17 @@ int dtp_launch_gemm_ws(const GemmParams& p, hipStream_t s) {
   if (p.splits > 1 && !(p.flags & GF_NOREDUCE)) return dtp_launch_splitk_reduce(p, s);
   return DTP_OK;
 }
+
+#else  // !DTP_EXPERIMENTAL: the entry points exist (engine / dispatcher link against them) and refuse
+void dtp_gemm_ws_init() {}
+size_t dtp_gemm_ws_packed_elems(int, int) { return 0; }
+int dtp_launch_pack_linear_ws(const f16*, int, f16*, int, int, hipStream_t) {
+  dtp_set_error("pack_linear_ws: gemmws_kernel (tile 55) is an experiment -- build with DTP_EXPERIMENTAL=1");
+  return DTP_ERR_ARG;
+}
+bool dtp_gemm_ws_supported(const GemmParams&, int) { return false; }
+int dtp_launch_gemm_ws(const GemmParams&, hipStream_t) {
+  dtp_set_error("gemm: tile 55 (gemmws_kernel) is an experiment -- build with DTP_EXPERIMENTAL=1");
+  return DTP_ERR_ARG;
+}
+#endif

@@ -725,7 +725,11 @@ int dtp_launch_reduce_groupnorm(const float* part, int splits, long long slab, i
   // (18 us at HW = 256, C = 1280, 8 slabs).  The two-pass form cuts the statistics pass along pixels AND channels (768 blocks), but
   // its second launch costs more than the parallelism returns: 124.9 vs 122.3 ms per stamp on the same box (+456 graph nodes at
   // ~5.5 us each) -- kept behind $DTP_GN_SMALL_TWOPASS=1 as the measured alternative.
+#ifdef DTP_EXPERIMENTAL
   static const bool small_fused = [] { const char* e = getenv("DTP_GN_SMALL_TWOPASS"); return !(e && e[0] && e[0] != '0'); }();
+#else
+  constexpr bool small_fused = true;
+#endif
   if (!dtp_reduce_groupnorm_supported(HW, C, groups) || (!small_fused && stats_ws && HW >= 32)) {  // reduce folded into the statistics pass, then the apply pass
     if (!stats_ws) { dtp_set_error("reduce+groupnorm: the two-pass form needs the statistics workspace"); return DTP_ERR_ARG; }
     const GnReduceSrc rd = {part, splits, slab, ldp, bias, R, ldr};

@@ -612,6 +612,9 @@ int dtp_set_option(dtp_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "autotune")) { c->autotune = value != 0; return DTP_OK; }
   if (!strcmp(name, "check_finite")) { c->check_finite = value != 0; return DTP_OK; }
   if (!strcmp(name, "fuse_gn_conv")) {
+#ifndef DTP_EXPERIMENTAL
+    if (value) { dtp_set_error("dtp_set_option: fuse_gn_conv is an experiment (slower: DESIGN.md 3.6) -- build with DTP_EXPERIMENTAL=1"); return DTP_ERR_ARG; }
+#endif
     if (!c->unet_progs.empty() || !c->enc_progs.empty() || !c->dec_progs.empty()) {
       dtp_set_error("dtp_set_option: fuse_gn_conv must be chosen before the first launch program is built");
       return DTP_ERR_STATE;

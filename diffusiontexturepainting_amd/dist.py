@@ -107,7 +107,7 @@ def gather_patches(local, n_total, rank, world, dst=0):
     global _gatherers_group
     if world == 1 and not dist.is_initialized():
         return local
-    group = dist.distributed_c10d._get_default_group()
+    group = dist.group.WORLD  # (the public handle of the default group; world > 1 without an initialised group raises inside torch)
     if _gatherers_group is not group:
         _gatherers.clear()
         _gatherers_group = group

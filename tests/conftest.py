@@ -12,6 +12,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    config.addinivalue_line("markers", "experimental: exercises a measured-and-switched-off experiment that only a DTP_EXPERIMENTAL=1 build of "
+                                       "libdtp.so contains (gemmws_kernel, GroupNorm on the halo conv's staged patch); skipped on the default build")
 
 
 @pytest.fixture(scope="session")

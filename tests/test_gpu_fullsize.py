@@ -226,12 +226,17 @@ def test_deduplicated_prefix_is_bit_identical(weights):
         assert outs[(1, b)][1] == outs[(0, b)][1] + 4  # one row-copy launch per evaluation (4 evaluations), nothing else changes
 
 
+@pytest.mark.experimental
 def test_groupnorm_applied_on_the_conv_input_patch(weights):
-    """Option fuse_gn_conv (off by default: it measured slower): GroupNorm + SiLU of a ResBlock applied by conv_halo_kernel on its
-    staged input patch instead of by an apply launch.  A 256^2 stamp with the option on must still match the oracle (level 0 of this
-    resolution has the 1024-pixel maps the fused path takes), and must differ from the default path only by fp16 roundings."""
+    """Option fuse_gn_conv (off by default: it measured slower; round 5: only in DTP_EXPERIMENTAL=1 builds): GroupNorm + SiLU of a ResBlock
+    applied by conv_halo_kernel on its staged input patch instead of by an apply launch.  A 256^2 stamp with the option on must still match
+    the oracle (level 0 of this resolution has the 1024-pixel maps the fused path takes), and must differ from the default path only by
+    fp16 roundings."""
+    from diffusiontexturepainting_amd import _lib
     from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
     from oracle import pipeline
+    if _lib.load().dtp_op_pack_linear_ws_elems(64, 64) == 0:
+        pytest.skip("experiment not in this build (DTP_EXPERIMENTAL=1 python -m diffusiontexturepainting_amd.build)")
     canvas, brush, cond, uncond, lat, eps = _inputs(1, 256, 900)
     st = dict(steps=4, context_pad=150, tg_steps=4, cfg_weight=2.0, tg_weight=1.0)
     outs = []
