@@ -1,6 +1,7 @@
 // Kernel-level C-ABI entry points (include/dtp.h, "kernel-level entry points") and the error slot.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 
@@ -221,6 +222,8 @@ int dtp_op_xattn(const void* X, const void* W1, const float* b1, const float* ln
   p.st_in = st_in; p.st_parts = st_parts; p.st_rows = N * S; p.ln_eps = ln_eps;
   p.W2 = (const f16*)W2; p.w2_bs = (long long)((C + 127) / 128 * 128) * 128; p.b2 = b2; p.R = (const f16*)R; p.ldr = C;
   p.Y = (f16*)Y; p.ldy = C; p.st_out = st_out; p.S = S; p.C = C; p.N = N; p.sm_valid = sm_valid; p.zero = (const f16*)g_ops.zero;
+  // column tiles per workgroup: the launcher's rule, or $DTP_XATTN_CT (read per call: the parity tests walk through several values)
+  if (const char* e = getenv("DTP_XATTN_CT")) p.ct = atoi(e);
   return dtp_launch_xattn(p, (hipStream_t)s);
 }
 

@@ -85,6 +85,12 @@ __device__ __forceinline__ void wait_lgkm(f16x4& a, f16x4& b, f16x4& c, f16x4& d
   asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N));
 }
 
+// the same as a plain wait + empty statements the fragments pass through (any number of fragments)
+template <int N>
+__device__ __forceinline__ void wait_lgkm_only() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void pass(f16x8& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pass(f16x4& a) { asm volatile("" : "+v"(a)); }
+
 // Both halves' values of x in every lane: lo = x of lane (l & 31), hi = x of lane (l & 31) + 32.  One v_permlane32_swap (VALU; __shfl_xor
 // is an LDS instruction and would enter the hand-counted lgkmcnt).  Inline asm: this hipcc returns the builtin's FIRST result for both
 // elements of __builtin_amdgcn_permlane32_swap's vector (a two-line kernel stores the same register twice), i.e. the builtin is unusable.
@@ -103,7 +109,8 @@ constexpr int v_row_step(int rs) {  // rows r, r + st, r + 2 st, r + 3 st are 64
 template <int D, int NS, int NW = 4>
 struct AdGeom {
   static constexpr int KC = D / 8;          // 16-byte chunks per K row
-  static constexpr int VC = KC + 1;         // per V row: the d columns + the chunk [1, 0, ..., 0] (row sums from the P V MFMAs)
+  static constexpr bool ONES = (D % 32) != 0;  // O^T has a spare row for the row sums (d = 160 = 5 x 32 has none: its sums are VALU adds)
+  static constexpr int VC = KC + (ONES ? 1 : 0);  // per V row: the d columns (+ the chunk [1, 0, ..., 0]: row sums from the P V MFMAs)
   static constexpr int RSK = KC * 16, RSV = VC * 16;  // row pitches (bytes)
   static constexpr int KS = (D + 15) / 16;  // k-steps of K Q^T
   static constexpr int DB = (D + 31) / 32;  // 32-row blocks of O^T (row D = the row sum: D % 32 != 0 for both head sizes)
@@ -113,8 +120,8 @@ struct AdGeom {
   static constexpr int NP = KC + VC;        // DMA pieces per tile: K image, then V image
   static constexpr int PW = (NP + NW - 1) / NW;  // per wave (waves >= NP % NW own one fewer when NP % NW != 0)
   static constexpr int LDS = NS * STAGE + 512;  // + a zeroed tail: the last row's reads beyond its chunks stay inside the allocation
-  static_assert(ST == 2 || ST == 4, "row permutation of the V image");
-  static_assert((NS - 1) * STAGE + IMGV + 256 < 65536, "ds_read immediates (the V base address already holds IMGK)");
+  // ds_read immediates are 16 bits: when the ring is larger, the slot offset goes into the address register (one add per half tile)
+  static constexpr bool BIGRING = (NS - 1) * STAGE + IMGV + 256 >= 65536;
 };
 
 // one tile's DMA pieces of this wave: piece pi = wave + 4 i -> LDS slot pi of ring slot `stage`; the lanes of a V row's ones chunk are off
@@ -135,12 +142,13 @@ __device__ __forceinline__ void issue_tile(const RS_T (&rs)[PW], char* smem, con
 // NW = 8: one K / V tile staged for 256 queries (half the DMA pieces and LDS writes per query); taken when the launch still has >= 8 x CUs
 // workgroups (a batched stamp's level 0), compiled for two workgroups per CU
 template <int D, int NS, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn_dma_kernel(const AttnParams p, const int qblocks) {
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : (D <= 80 ? 2 : 1))) void attn_dma_kernel(const AttnParams p, const int qblocks) {
   using G = AdGeom<D, NS, NW>;
   constexpr int NTHR = 64 * NW;
   constexpr int KC = G::KC, VC = G::VC, RSK = G::RSK, RSV = G::RSV, KS = G::KS, DB = G::DB, ST = G::ST, IMGK = G::IMGK, STAGE = G::STAGE,
                 NP = G::NP, PW = G::PW;
-  static_assert(D == 40 || D == 80, "head sizes of UNet levels 0 / 1");
+  static_assert(D == 40 || D == 80 || D == 160, "head sizes of UNet levels 0 / 1 / 2-3");
+  constexpr bool ONES = G::ONES, BIGRING = G::BIGRING;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -164,7 +172,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn
   // ones chunks of the V images: LDS row r of slot s, chunk KC
   for (int i = tid; i < G::LDS / 16; i += NTHR) ((f32x4*)smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  for (int i = tid; i < NS * 64; i += NTHR) *(f16*)(smem + (i >> 6) * STAGE + IMGK + (i & 63) * RSV + KC * 16) = (f16)1.0f;
+  if constexpr (ONES)
+    for (int i = tid; i < NS * 64; i += NTHR) *(f16*)(smem + (i >> 6) * STAGE + IMGK + (i & 63) * RSV + KC * 16) = (f16)1.0f;
 
   // ---- this wave's DMA pieces: piece pi = wave + 4 i of a tile (pi < KC: K image, else V image), 64 lanes x 16 bytes, lane-linear in LDS
   constexpr int OOB = (int)0x80000000u;
@@ -180,13 +189,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn
     if (isk) {
       const int row = g / KC, cpos = g - row * KC;
       key = row;
-      c = (D == 80) ? (cpos ^ ((key >> 3) & 1)) : cpos;
+      c = (D == 80) ? (cpos ^ ((key >> 3) & 1)) : (D == 160) ? (cpos ^ ((key >> 2) & 3)) : cpos;
     } else {
       const int row = g / VC, cpos = g - row * VC;
       c = cpos;
       on = cpos < KC;  // the ones chunk is never written by the DMA
       if (ST == 4) key = (row & ~15) + 4 * (row & 3) + ((row >> 2) & 3);
-      else key = (row & ~7) + 4 * (row & 1) + ((row >> 1) & 3);
+      else if (ST == 2) key = (row & ~7) + 4 * (row & 1) + ((row >> 1) & 3);
+      else key = row;
     }
     voff[i] = on ? (key * (isk ? p.ldk : p.ldv) + c * 8) * 2 : -1;
     rs[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(isk ? Kb : Vb), 0, OOB, 0x00020000);
@@ -226,9 +236,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn
 
   // ---- per-lane fragment addresses (ring slot 0, key block 0); everything else is an immediate
   const uint32_t sbase = lds_addr(smem);
-  const uint32_t kaddr0 = sbase + lq * RSK + ((D == 80 ? (hf ^ ((lq >> 3) & 1)) : hf) << 4);
+  // K fragment of k-step ks = chunk 2 ks + hf of the lane's key row.  d = 80: the chunk sits at c ^ ((k >> 3) & 1) -- only the hf bit
+  // moves, one base register; d = 160: at c ^ ((k >> 2) & 3) -- the two low chunk bits (2 (ks & 1) + hf) move: one base per k-step
+  // parity, and the immediate carries (ks >> 1) * 64 bytes
+  const uint32_t kaddr0 = sbase + lq * RSK + ((D == 80 ? (hf ^ ((lq >> 3) & 1)) : D == 160 ? (hf ^ ((lq >> 2) & 3)) : hf) << 4);
+  const uint32_t kaddr1 = sbase + lq * RSK + (((2 + hf) ^ ((lq >> 2) & 3)) << 4);  // d = 160, odd k-steps
   const int li = lane & 15, lg = lane >> 4;  // tr-read: lane li of 16-lane group lg (lg & 1: d sub-block, lg >> 1 = hf)
-  const uint32_t vaddr0 = sbase + IMGK + (ST * (li >> 2) + hf) * RSV + (16 * (lg & 1) + 4 * (li & 3)) * 2;
+  const uint32_t vaddr0 = sbase + IMGK + (ST == 1 ? 4 * hf + (li >> 2) : ST * (li >> 2) + hf) * RSV + (16 * (lg & 1) + 4 * (li & 3)) * 2;
 
   f32x16 oacc[DB];
 #pragma unroll
@@ -239,6 +253,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn
 #pragma unroll
   for (int r = 0; r < 16; ++r) mvec[r] = 0.f;
   constexpr float THR = 6.0f;  // a reference moves when a score exceeds it by 2^THR (fp16 P holds 2^16)
+  float lsum[4] = {0.f, 0.f, 0.f, 0.f};  // !ONES (d = 160): this lane's share of the row sum
 
   constexpr int WSTEP = (ST == 4 ? 2 : 8) * RSV;  // a V^T fragment's second read: keys 8 further on
   constexpr int NVH = 4 * DB;                      // V reads per half tile
@@ -252,6 +267,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn
     for (int db = 0; db < DB; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    if constexpr (!ONES) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lsum[i] *= alpha;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) nxt[r] -= delta;
 #pragma unroll
@@ -262,20 +281,27 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn
   // fragments of this half at va + VOFF.  The instruction order is pinned group by group (sched_barrier): left alone, hipcc gathers every
   // wait in front of the first MFMA.  VALU work that needs no fragment comes first (it covers the LDS latency of the requests), then
   // every MFMA is followed by its share of the exponentials / packs / maxima.  Returns this lane's maximum over nxt.
-  auto half_step = [&](f32x16& cur, f32x16& nxt, auto koffc, auto voffc) -> float {
-    constexpr int KOFF = decltype(koffc)::value, VOFF = decltype(voffc)::value;
+  auto half_step = [&](f32x16& cur, f32x16& nxt, auto kslotc, auto koffc, auto vslotc, auto voffc) -> float {
+    // ring slot offsets: immediates, or (ring beyond the 16-bit immediate range: d = 160) one add into the address registers
+    constexpr int KSLOT = decltype(kslotc)::value * STAGE, VSLOT = decltype(vslotc)::value * STAGE;
+    constexpr int KOFF = decltype(koffc)::value + (BIGRING ? 0 : KSLOT), VOFF = decltype(voffc)::value + (BIGRING ? 0 : VSLOT);
+    const uint32_t ka0 = kaddr0 + (BIGRING ? KSLOT : 0), ka1 = kaddr1 + (BIGRING ? KSLOT : 0), va0 = vaddr0 + (BIGRING ? VSLOT : 0);
     f16x8 kf[KS];
     f16x4 vf[2][DB][2];
 #ifndef DTP_AD_NO_KREAD  // (diagnostic builds only: tools/attn_variants.sh)
-    static_for<KS>([&](auto ksc) { constexpr int ks = decltype(ksc)::value; kf[ks] = ld_b128<KOFF + ks * 32>(kaddr0); });
+    static_for<KS>([&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      if constexpr (D == 160) kf[ks] = ld_b128<KOFF + (ks >> 1) * 64>((ks & 1) ? ka1 : ka0);
+      else kf[ks] = ld_b128<KOFF + ks * 32>(ka0);
+    });
 #else
     static_for<KS>([&](auto ksc) { constexpr int ks = decltype(ksc)::value; kf[ks] = qf[ks]; });
 #endif
     static_for<2 * DB>([&](auto ic) {
       constexpr int i = decltype(ic)::value, s = i / DB, db = i % DB, off = VOFF + 16 * s * RSV + db * 64;
 #ifndef DTP_AD_NO_VREAD
-      vf[s][db][0] = ld_tr<off>(vaddr0);
-      vf[s][db][1] = ld_tr<off + WSTEP>(vaddr0);
+      vf[s][db][0] = ld_tr<off>(va0);
+      vf[s][db][1] = ld_tr<off + WSTEP>(va0);
 #else
       vf[s][db][0] = f16x4{qf[0][0], qf[0][1], qf[0][2], qf[0][3]};
       vf[s][db][1] = f16x4{qf[0][4], qf[0][5], qf[0][6], qf[0][7]};
@@ -308,10 +334,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn
     // chained back to back, A's three MFMAs ran at the accumulator's latency, not at the pipe's rate: tools/micro/attn_probe2.hip) --
     // with the second eight exponentials + their packs spread behind the first KS + DB of them and the next half's row maximum
     // behind the last DB.
-    if constexpr (DB == 2) wait_lgkm<NVH / 2>(vf[0][0][0], vf[0][0][1], vf[0][1][0], vf[0][1][1]);
-    else wait_lgkm<NVH / 2>(vf[0][0][0], vf[0][0][1], vf[0][1][0], vf[0][1][1], vf[0][2][0], vf[0][2][1]);
-    if constexpr (KS == 3) wait_lgkm<NVH / 2>(kf[0], kf[1], kf[2]);
-    else wait_lgkm<NVH / 2>(kf[0], kf[1], kf[2], kf[3], kf[4]);
+    wait_lgkm_only<NVH / 2>();
+    static_for<KS>([&](auto ksc) { pass(kf[decltype(ksc)::value]); });
+    static_for<DB>([&](auto dbc) { pass(vf[0][decltype(dbc)::value][0]); pass(vf[0][decltype(dbc)::value][1]); });
     auto mfma_a = [&](auto ksc) {
       constexpr int ks = decltype(ksc)::value;
 #ifndef DTP_AD_NO_MFMA
@@ -343,12 +368,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn
       if (i == NFIRST - 1) pack(1);
       __builtin_amdgcn_sched_barrier(0);
     });
-    if constexpr (DB == 2) wait_lgkm<0>(vf[1][0][0], vf[1][0][1], vf[1][1][0], vf[1][1][1]);
-    else wait_lgkm<0>(vf[1][0][0], vf[1][0][1], vf[1][1][0], vf[1][1][1], vf[1][2][0], vf[1][2][1]);
+    wait_lgkm_only<0>();
+    static_for<DB>([&](auto dbc) { pass(vf[1][decltype(dbc)::value][0]); pass(vf[1][decltype(dbc)::value][1]); });
     float mloc = 0.f;
     static_for<DB>([&](auto dbc) {
       constexpr int db = decltype(dbc)::value;
       mfma_b(IC<1>{}, dbc);
+      if constexpr (!ONES) {  // d = 160: the row sums are VALU adds
+        constexpr int a0 = (16 * db) / DB, a1 = (16 * (db + 1)) / DB;
+#pragma unroll
+        for (int i = a0; i < a1; ++i) lsum[i & 3] += pe[i];
+      }
       constexpr int m0 = (8 * db) / DB, m1 = (8 * (db + 1)) / DB;  // 8 register pairs of nxt over the last DB MFMAs
 #pragma unroll
       for (int i = m0; i < m1; ++i) {
@@ -358,7 +388,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn
       }
       asm volatile("" : "+v"(mloc));  // (keeps the chain here, under the MFMAs: hipcc otherwise sinks it behind the caller's branch)
       __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);   // the MFMA first: the maxima read the A chain's result, which needs its latency
-      __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x2, 16, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
     return mloc;
@@ -377,7 +407,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn
   f32x16 sA, sB;
   {
     f16x8 kf[KS];
-    static_for<KS>([&](auto ksc) { constexpr int ks = decltype(ksc)::value; kf[ks] = ld_b128<ks * 32>(kaddr0); });
+    static_for<KS>([&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      if constexpr (D == 160) kf[ks] = ld_b128<(ks >> 1) * 64>((ks & 1) ? kaddr1 : kaddr0);
+      else kf[ks] = ld_b128<ks * 32>(kaddr0);
+    });
     static_for<KS>([&](auto ksc) {
       constexpr int ks = decltype(ksc)::value;
       wait_lgkm<KS - 1 - ks>(kf[ks]);
@@ -401,7 +435,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn
       const int t = t0 + S;
       if (t < T) {
         DTP_AD_STAMP(0)
-        const float mB = half_step(sA, sB, IC<S * STAGE + 32 * RSK>{}, IC<S * STAGE>{});
+        const float mB = half_step(sA, sB, IC<S>{}, IC<32 * RSK>{}, IC<S>{}, IC<0>{});
         DTP_AD_STAMP(1)
 #ifndef DTP_AD_NO_CHECK
         if (__any(mB > THR)) rebase(sB, mB, THR);
@@ -429,7 +463,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn
 #endif
         DTP_AD_STAMP(5)
         // (the last tile's second half multiplies whatever the next slot holds -- finite -- into scores nobody uses, without a check)
-        const float mA = half_step(sB, sA, IC<SN * STAGE>{}, IC<S * STAGE + 32 * RSV>{});
+        const float mA = half_step(sB, sA, IC<SN>{}, IC<0>{}, IC<S>{}, IC<32 * RSV>{});
         DTP_AD_STAMP(6)
 #ifndef DTP_AD_NO_CHECK
         if (t + 1 < T && __any(mA > THR)) rebase(sA, mA, THR);
@@ -440,10 +474,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (D <= 40 ? 3 : 2)) void attn
   }
 
   // ---- normalise and store: lane = query row, registers = 4 consecutive d per group; O^T row D = the row sum (lower half-wave)
-  constexpr int LDB = D / 32, LREG = 4 * ((D % 32) >> 3);  // row D = 32 LDB + (r & 3) + 8 (r >> 2) + 4 hf  ->  hf = 0, r = LREG (D % 8 == 0)
-  static_assert((D % 32) % 8 == 0 && ((D % 32) & 4) == 0, "the row sum sits in the lower half-wave");
   float l;
-  { float lo, hi; both_halves(oacc[LDB][LREG], lo, hi); l = lo; }
+  if constexpr (ONES) {
+    constexpr int LDB = D / 32, LREG = 4 * ((D % 32) >> 3);  // row D = 32 LDB + (r & 3) + 8 (r >> 2) + 4 hf  ->  hf = 0, r = LREG (D % 8 == 0)
+    static_assert((D % 32) % 8 == 0 && ((D % 32) & 4) == 0, "the row sum sits in the lower half-wave");
+    float lo, hi;
+    both_halves(oacc[LDB][LREG], lo, hi);
+    l = lo;
+  } else {
+    float lo, hi;
+    both_halves((lsum[0] + lsum[1]) + (lsum[2] + lsum[3]), lo, hi);
+    l = lo + hi;
+  }
   if (q < p.Sq) {
     const float inv = 1.0f / l;
     f16* const Ob = p.O + p.obs * b + (size_t)q * p.ldo + h * D;
@@ -478,8 +520,8 @@ int launch(const AttnParams& p, hipStream_t s) {
 
 // the LDS-DMA kernel takes the launch when every tile is a full 64-key tile and the 32-bit DMA offsets reach the whole sequence
 bool dtp_attention_dma_supported(const AttnParams& p) {
-  if (p.D != 40 && p.D != 80) return false;
-  if (p.Skv < 128 || (p.Skv & 63) || p.Sq < 1) return false;
+  if (p.D != 40 && p.D != 80 && p.D != 160) return false;
+  if (p.Skv < (p.D == 160 ? 64 : 128) || (p.Skv & 63) || p.Sq < 1) return false;
   if ((p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.ldo & 3)) return false;
   if (((uintptr_t)p.K & 15) || ((uintptr_t)p.V & 15) || ((uintptr_t)p.Q & 15) || ((uintptr_t)p.O & 7)) return false;
   if ((p.kbs & 7) || (p.vbs & 7) || (p.qbs & 7) || (p.obs & 3)) return false;
@@ -498,5 +540,6 @@ int dtp_launch_attention_dma(const AttnParams& p, hipStream_t s) {
   static const int nw8_env = [] { const char* e = getenv("DTP_ATTN_NW8"); return e ? atoi(e) : -1; }();
   const bool nw8 = nw8_env >= 0 ? nw8_env != 0 : (long long)((p.Sq + 255) / 256) * p.H * p.B >= 8LL * cus;
   if (p.D == 40) return nw8 ? launch<40, 4, 8>(p, s) : launch<40, 4, 4>(p, s);
-  return launch<80, 3, 4>(p, s);
+  if (p.D == 80) return launch<80, 3, 4>(p, s);
+  return launch<160, 3, 4>(p, s);  // levels 2-3 (S = 256 / 64): one 128-query workgroup per CU at most, the whole launch is latency
 }

@@ -259,7 +259,9 @@ struct XattnParams {
   float* st_out;                     // [ceil(C/128)][st_rows][2] partials of the stored rows, or null
   int S, C, N, sm_valid;             // rows per sample, channels, samples, valid columns per 16-group
   const f16* zero;                   // >= 16 bytes of zeros
+  int ct;                            // consecutive 128-column tiles per workgroup (the probability tile is computed once per workgroup); 0 = the launcher chooses
 };
+int dtp_xattn_tiles_per_wg(int S, int C, int N);
 bool dtp_xattn_supported(const XattnParams& p);
 int dtp_launch_xattn(const XattnParams& p, hipStream_t s);
 void dtp_xattn_init();

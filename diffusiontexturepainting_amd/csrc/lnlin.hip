@@ -360,9 +360,10 @@ bool dtp_lnlin_supported(const GemmParams& p, int nsplit) {
   if (nsplit < 1) return false;
   const int nch = geglu ? (p.N >> 6) : (p.N >> 5);
   if (nsplit > nch || (nch + nsplit - 1) / nsplit > MAX_CHUNKS) return false;
-  // every column range must own at least one chunk: a workgroup with an empty range returns before it writes its GF_ROWSTATS partial,
-  // and the consumer sums ALL `nsplit` partials (round-4 advisor: nch = 20 with 6 or 8 ranges left the last 1-2 partials stale)
-  if ((nsplit - 1) * ((nch + nsplit - 1) / nsplit) >= nch) return false;
+  // with GF_ROWSTATS every column range must own at least one chunk: a workgroup with an empty range returns before it writes its
+  // partial, and the consumer sums ALL `nsplit` partials (round-4 advisor: nch = 20 with 6 or 8 ranges left the last 1-2 partials
+  // stale).  Without the statistics an empty range is only an idle workgroup (shipped tune entries such as N = 960 in 24 ranges stay valid).
+  if ((p.flags & GF_ROWSTATS) && (nsplit - 1) * ((nch + nsplit - 1) / nsplit) >= nch) return false;
   if ((p.flags & GF_ROWSTATS) && nsplit > (p.N + 63) / 64) return false;  // the consumer's table has room for one partial per 64 columns
   return true;
 }

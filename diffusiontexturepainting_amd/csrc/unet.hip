@@ -253,7 +253,16 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
   // The fused kernel recomputes the score tile once per 128-column tile of the output: it pays where the pair is launch-bound (few
   // workgroups: levels 1-3 of a batch-1 stamp, every level at 256^2) and loses where the grid already fills the chip several times
   // (level 0 at 512^2: +1.3 ms per stamp; batch 8: +17 ms per batch with everything fused -- same-box A/B).
-  const long long xa_wgs = (long long)((S + 63) / 64) * ((C + 127) / 128) * N;
+  // Round 5: a workgroup may take several column tiles (one probability tile, no recomputation) -- taken when the whole launch is then a
+  // single round of workgroups (level 0 at batch 1: 64 row blocks x 3 samples x all three tiles = 192 workgroups, one launch instead of
+  // two grouped GEMMs); otherwise one tile per workgroup under the old gate.
+  const int nt = (C + 127) / 128;
+  int ct = dtp_xattn_tiles_per_wg(S, C, N);
+  if ((long long)((S + 63) / 64) * ((nt + ct - 1) / ct) * N > b.c->num_cu) ct = 1;
+  static const bool ct_off = [] { const char* e = getenv("DTP_XATTN_CT1"); return e && e[0] && e[0] != '0'; }();  // A/B: one tile per workgroup as in round 4
+  if (ct_off) ct = 1;
+  xp.ct = ct;
+  const long long xa_wgs = (long long)((S + 63) / 64) * ((nt + ct - 1) / ct) * N;
   if (b.c->fuse_xattn && xa_wgs <= 2LL * b.c->num_cu && st2.buf && st2.parts > 0 && st2.M == N * S && dtp_xattn_supported(xp)) {
     // one launch: scores + group softmax + value-output product + residual (xattn.hip); the probabilities never leave LDS
     RC(b.alloc_stats((long long)N * S, C, st3));
@@ -261,9 +270,9 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
     if (!y3.p) return DTP_ERR_HIP;
     xp.Y = y3.p; xp.ldy = y3.ld; xp.st_out = st3.buf;
     st3.parts = (C + 127) / 128; st3.M = N * S;
-    const double tiles = (double)((C + 127) / 128);
+    const double tiles = (double)((nt + ct - 1) / ct);  // the scores are computed once per workgroup
     b.push(PK_XATTN, 2.0 * N * S * 128.0 * C * (tiles + 1.0), 2.0 * N * (3.0 * S * C + 2.0 * 128 * C),
-           [=](hipStream_t s, int) { return dtp_launch_xattn(xp, s); }, "xattn M=" + std::to_string(S) + " C=" + std::to_string(C) + " x" + std::to_string(N));
+           [=](hipStream_t s, int) { return dtp_launch_xattn(xp, s); }, "xattn M=" + std::to_string(S) + " C=" + std::to_string(C) + " x" + std::to_string(N) + (ct > 1 ? " ct=" + std::to_string(ct) : ""));
     b.release_stats(st2);
     b.release(y2);
   } else {

@@ -10,6 +10,10 @@
 // before phase 1 started.  Same MFMA mapping, LDS image (128-byte rows, XOR-swizzled 16-byte chunks) and epilogue arithmetic as
 // gemm_kernel (gemm_conv.hip): against the unfused pair on 4-wave tiles the result is bit-identical -- P is rounded to fp16 exactly
 // where the first GEMM would have stored it.
+// Round 5: a workgroup may own SEVERAL consecutive 128-column tiles (XattnParams::ct): the probability tile is computed once and multiplied
+// with one W2 tile after the other (the next tile's DMA runs under the current tile's MFMAs, into the ring phase 1 no longer needs).
+// UNet level 0 (C = 320: three column tiles, 64 row blocks x 3 samples) then is ONE 192-workgroup launch without any recomputation
+// instead of the two grouped GEMMs it used to be (the fused form lost there: it recomputed the scores three times).
 // Reference: diffusers CrossAttention (attn2 of BasicTransformerBlock) as called from trt_inference/models.py:1097-1139 (the UNet
 // engine); the algebraic fusion itself is described in unet.hip transformer().
 #include "common.h"
@@ -43,8 +47,11 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile_m = blockIdx.x, tile_n = blockIdx.y, smp = blockIdx.z;
-  const int m0 = tile_m * XBM, n0 = tile_n * XBN;
+  const int tile_m = blockIdx.x, smp = blockIdx.z;
+  const int ntiles = (p.C + XBN - 1) / XBN;
+  const int ct0 = blockIdx.y * p.ct, ct1 = min(ct0 + p.ct, ntiles);  // this workgroup's column tiles
+  const int m0 = tile_m * XBM;
+  int tile_n = ct0, n0 = ct0 * XBN;
   const f16* X = p.X + (size_t)smp * p.S * p.ldx;
   const f16* W1 = p.W1 + (size_t)smp * p.w1_bs;
   const f16* W2 = p.W2 + (size_t)smp * p.w2_bs;
@@ -56,8 +63,8 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
   constexpr int NC = XBN / 8;  // 16: a thread owns the same 8-column chunk in every epilogue iteration
   constexpr int EIT = XBM * NC / 256;  // 4
   const int nc = tid % NC;
-  const int n = n0 + nc * 8;
-  const bool col_ok = (n + 8 <= p.C);  // C % 8 == 0
+  int n = n0 + nc * 8;
+  bool col_ok = (n + 8 <= p.C);  // C % 8 == 0
   float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (col_ok && p.b2) {
     const f32x4 t0 = *(const f32x4*)(p.b2 + n), t1 = *(const f32x4*)(p.b2 + n + 4);
@@ -91,14 +98,18 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) w1_off[i] = ((i * 32 + lrow) * p.C + kc) * 2;
-  // the whole W2 tile now: it lands while phase 1 runs (rows beyond C are zero padding of the per-sample matrices)
+  // one W2 tile (rows beyond C are zero padding of the per-sample matrices).  The first one now: it lands while phase 1 runs.
+  char* const w2alt = ring + 32768;  // the second W2 buffer: ring memory behind the staging tile, free once phase 1 is over
+  auto issue_w2 = [&](int ct, char* dst) {
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int vo = ((n0 + i * 32 + lrow) * 128 + kc) * 2;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (lds_ptr_t)(w2s + kb * (XBN * 128) + (i * 32 + wave * 8) * 128), 16, vo, kb * 128, 0, 0);
-    }
+      for (int i = 0; i < 4; ++i) {
+        const int vo = ((ct * XBN + i * 32 + lrow) * 128 + kc) * 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (lds_ptr_t)(dst + kb * (XBN * 128) + (i * 32 + wave * 8) * 128), 16, vo, kb * 128, 0, 0);
+      }
+  };
+  issue_w2(ct0, w2s);
   auto issue = [&](int stage, int kb) {
     char* As = ring + stage * XSTAGE;
 #pragma unroll
@@ -235,51 +246,85 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
       *(f16x8*)(ps + (nc >> 3) * (XBM * 128) + ml * 128 + (((nc & 7) ^ ((ml >> 1) & 7)) << 4)) = o;
     }
   }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  __syncthreads();  // P complete (the W2 tile landed before the first phase-1 barrier)
+  __syncthreads();  // P complete (the first W2 tile landed before the first phase-1 barrier)
 
-  // ---- phase 2: y3 tile = P W2^T over K = 128
-  kblock((uint32_t)(ps - ring), (uint32_t)(w2s - ring));
-  kblock((uint32_t)(ps - ring) + XBM * 128, (uint32_t)(w2s - ring) + XBN * 128);
-  __syncthreads();  // everyone has read the staging tile of epilogue 1
-  stage_acc();
-  __syncthreads();
-
-  // ---- epilogue 2: + bias + residual, fp16 store, per-row (sum, sum of squares) of the stored values for the next LayerNorm fold
-#pragma unroll
-  for (int it = 0; it < EIT; ++it) {
-    const int ml = (tid + it * 256) / NC, m = m0 + ml;
-    const bool active = (m < p.S) && col_ok;
-    float s1 = 0.f, s2 = 0.f;
-    if (active) {
-      const f16x8 v = *(const f16x8*)(stg + ml * XSLD + nc * 8);
-      float x[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] += bv[e];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] += (float)rv[it][e];
-      f16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        o[e] = (f16)x[e];
-        const float f = (float)o[e];
-        s1 += f; s2 += f * f;
-      }
-      *(f16x8*)(p.Y + (row0 + m) * p.ldy + n) = o;
+  // ---- per column tile: phase 2 (y3 tile = P W2^T over K = 128) + epilogue 2
+  for (int ct = ct0; ct < ct1; ++ct) {
+    char* const w2cur = ((ct - ct0) & 1) ? w2alt : w2s;
+    if (ct > ct0) {
+      // this tile's W2 has landed (for every wave), and everyone has left the previous tile's staging tile and W2 buffer
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
-    if (p.st_out) {  // NC consecutive lanes hold one row of this column tile: fixed-order shuffle reduce
+    // the next tile: its W2 into the other buffer (last read one tile ago), its bias chunk and residual rows into registers -- all of it
+    // lands under this tile's MFMAs and epilogue
+    const bool more = ct + 1 < ct1;
+    float bvn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    f16x8 rvn[EIT];
+    const int nn = (ct + 1) * XBN + nc * 8;
+    const bool col_okn = more && (nn + 8 <= p.C);
+    if (more) {
+      issue_w2(ct + 1, ((ct - ct0) & 1) ? w2s : w2alt);
+      if (col_okn && p.b2) {
+        const f32x4 t0 = *(const f32x4*)(p.b2 + nn), t1 = *(const f32x4*)(p.b2 + nn + 4);
 #pragma unroll
-      for (int o = NC / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-      if (nc == 0 && m < p.S) {
-        p.st_out[((size_t)tile_n * p.st_rows + row0 + m) * 2] = s1;
-        p.st_out[((size_t)tile_n * p.st_rows + row0 + m) * 2 + 1] = s2;
+        for (int e = 0; e < 4; ++e) { bvn[e] = t0[e]; bvn[4 + e] = t1[e]; }
+      }
+#pragma unroll
+      for (int it = 0; it < EIT; ++it) {
+        const int mr = min(m0 + (tid + it * 256) / NC, p.S - 1);
+        rvn[it] = col_okn ? *(const f16x8*)(p.R + (row0 + mr) * p.ldr + nn) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
       }
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    kblock((uint32_t)(ps - ring), (uint32_t)(w2cur - ring));
+    kblock((uint32_t)(ps - ring) + XBM * 128, (uint32_t)(w2cur - ring) + XBN * 128);
+    __syncthreads();  // everyone has read the staging tile of the previous epilogue
+    stage_acc();
+    __syncthreads();
+
+    // ---- epilogue 2: + bias + residual, fp16 store, per-row (sum, sum of squares) of the stored values for the next LayerNorm fold
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      const int ml = (tid + it * 256) / NC, m = m0 + ml;
+      const bool active = (m < p.S) && col_ok;
+      float s1 = 0.f, s2 = 0.f;
+      if (active) {
+        const f16x8 v = *(const f16x8*)(stg + ml * XSLD + nc * 8);
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += bv[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += (float)rv[it][e];
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o[e] = (f16)x[e];
+          const float f = (float)o[e];
+          s1 += f; s2 += f * f;
+        }
+        *(f16x8*)(p.Y + (row0 + m) * p.ldy + n) = o;
+      }
+      if (p.st_out) {  // NC consecutive lanes hold one row of this column tile: fixed-order shuffle reduce
+#pragma unroll
+        for (int o = NC / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if (nc == 0 && m < p.S) {
+          p.st_out[((size_t)ct * p.st_rows + row0 + m) * 2] = s1;
+          p.st_out[((size_t)ct * p.st_rows + row0 + m) * 2 + 1] = s2;
+        }
+      }
+    }
+    // hand over to the next tile
+    n = nn; col_ok = col_okn;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = bvn[e];
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) rv[it] = rvn[it];
   }
 }
 
@@ -293,8 +338,22 @@ bool dtp_xattn_supported(const XattnParams& p) {
          (size_t)p.S * p.ldx * 2 < ((size_t)1 << 31) && (size_t)(p.C + 128) * 256 < ((size_t)1 << 31);  // 32-bit lane offsets of the DMA
 }
 
-int dtp_launch_xattn(const XattnParams& p, hipStream_t s) {
-  if (!dtp_xattn_supported(p)) { dtp_set_error("xattn: unsupported problem (C=%d S=%d)", p.C, p.S); return DTP_ERR_ARG; }
-  hipLaunchKernelGGL(xattn_kernel, dim3((p.S + XBM - 1) / XBM, (p.C + XBN - 1) / XBN, p.N), dim3(256), XLDS, s, p);
+// column tiles per workgroup: as many as still leave ~0.6 x 256 workgroups (fewer recomputations of the probability tile; below that the
+// launch no longer fills the chip and a workgroup's serial chain of tiles decides)
+int dtp_xattn_tiles_per_wg(int S, int C, int N) {
+  const int rb = ((S + XBM - 1) / XBM) * N, nt = (C + XBN - 1) / XBN;
+  int ct = 1;
+  for (int c = 2; c <= nt; ++c)
+    if (rb * ((nt + c - 1) / c) >= 160) ct = c;
+  return ct;
+}
+
+int dtp_launch_xattn(const XattnParams& pin, hipStream_t s) {
+  if (!dtp_xattn_supported(pin)) { dtp_set_error("xattn: unsupported problem (C=%d S=%d)", pin.C, pin.S); return DTP_ERR_ARG; }
+  XattnParams p = pin;
+  const int nt = (p.C + XBN - 1) / XBN;
+  if (p.ct < 1) p.ct = dtp_xattn_tiles_per_wg(p.S, p.C, p.N);
+  if (p.ct > nt) p.ct = nt;
+  hipLaunchKernelGGL(xattn_kernel, dim3((p.S + XBM - 1) / XBM, (nt + p.ct - 1) / p.ct, p.N), dim3(256), XLDS, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }

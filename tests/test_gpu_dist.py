@@ -59,7 +59,9 @@ def _worker(rank, world, port, q):
     patches = _stamp_shard(model, mine, lat[lo:hi], eps[:, lo:hi].contiguous())
     out = D.gather_patches(patches, N_TOTAL, rank, world)
     D.barrier()
-    q.put((rank, None if out is None else out.cpu()))
+    # by value (numpy), not as a shared-memory torch tensor: the receiver of a shared tensor connects back to THIS process for the file
+    # descriptor, and a worker that has already exited answers with EOFError (seen in round 5)
+    q.put((rank, None if out is None else out.cpu().numpy()))
     torch.distributed.destroy_process_group()
 
 
@@ -92,8 +94,9 @@ def test_two_ranks_on_one_gpu_match_a_single_process(tmp_path, monkeypatch):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert res[1] is None and res[0].shape == (N_TOTAL, R, R, 3) and res[0].dtype == torch.uint8
-    assert torch.equal(res[0], ref)
+    got = torch.from_numpy(res[0])
+    assert res[1] is None and got.shape == (N_TOTAL, R, R, 3) and got.dtype == torch.uint8
+    assert torch.equal(got, ref)
 
 
 def _run_bench(extra_env, *args, timeout=900):

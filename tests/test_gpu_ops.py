@@ -329,6 +329,29 @@ def test_fused_cross_attention_pair_matches_the_two_gemms(ops, nb, s, c):
     close(got_y, ref, tol=4e-3)
 
 
+@pytest.mark.parametrize("nb,s,c,ct", [(3, 4096, 320, 2), (2, 300, 640, 5), (1, 130, 1280, 3), (3, 256, 1280, 10), (2, 64, 320, 3)])
+def test_fused_cross_attention_several_column_tiles_per_workgroup(ops, nb, s, c, ct, monkeypatch):
+    """xattn_kernel with `ct` consecutive 128-column tiles per workgroup (round 5: the probability tile is computed once, the W2 tiles
+    alternate between two LDS buffers, bias / residual operands of the next tile are prefetched): bit-identical to one tile per
+    workgroup -- same MFMA order per output element -- for full and ragged tile groups (3 tiles in groups of 2, 10 in groups of 3)."""
+    g = torch.Generator().manual_seed(177)
+    x = (rnd(nb * s, c, seed=178) * 1.3 + 0.2).cuda()
+    w1 = rnd(nb, 128, c, seed=179, scale=2.0 * c ** -0.5).float()
+    b1 = 0.3 * torch.randn(nb, 128, generator=g)
+    w2 = rnd(nb, c, 128, seed=180, scale=0.1).float()
+    b2 = torch.randn(c, generator=g)
+    xf = x.float().cpu()
+    st_in = torch.stack([torch.stack([xf.sum(1), (xf ** 2).sum(1)], dim=1)]).cuda()
+    w1p = torch.cat([ops.pack_linear(w1[b].cuda()) for b in range(nb)], dim=0).contiguous()
+    lns = ops.rowsum(w1p, c)
+    w2p = torch.cat([ops.pack_linear(w2[b].cuda()) for b in range(nb)], dim=0).contiguous()
+    monkeypatch.setenv("DTP_XATTN_CT", "1")
+    ref_y, ref_st = ops.xattn(x, w1p, b1.reshape(-1).cuda(), lns, st_in, w2p, b2.cuda(), nb, row_stats=True)
+    monkeypatch.setenv("DTP_XATTN_CT", str(ct))
+    got_y, got_st = ops.xattn(x, w1p, b1.reshape(-1).cuda(), lns, st_in, w2p, b2.cuda(), nb, row_stats=True)
+    assert torch.equal(got_y, ref_y) and torch.equal(got_st, ref_st)
+
+
 def test_gemm_batched_residual(ops):
     """Second half: P [b*M, 128] times a per-entry [N, 128] matrix, + bias + residual."""
     nb, m, n = 3, 130, 320
@@ -689,7 +712,8 @@ def test_attention_eight_wave_workgroups_on_a_batched_launch(ops):
 
 
 @pytest.mark.parametrize("b,sq,skv,heads,d", [(3, 4096, 4096, 8, 40), (3, 1024, 1024, 8, 80), (1, 200, 256, 8, 40), (2, 40, 128, 4, 80),
-                                              (1, 1024, 1024, 5, 40), (2, 300, 640, 8, 80), (24, 256, 256, 8, 40), (130, 500, 512, 8, 40)])
+                                              (1, 1024, 1024, 5, 40), (2, 300, 640, 8, 80), (24, 256, 256, 8, 40), (130, 500, 512, 8, 40),
+                                              (3, 256, 256, 8, 160), (3, 64, 64, 8, 160), (1, 200, 320, 8, 160), (2, 64, 128, 3, 160)])
 def test_attention_dma_kernel(ops, b, sq, skv, heads, d):
     """attn_dma_kernel (round 5: K / V tiles by LDS-DMA, V^T fragments by ds_read_b64_tr_b16, the softmax shift in the MFMA's C operand):
     the UNet's level-0 / level-1 launches at batch 1, ragged query blocks, Sq != Skv, a (batch x heads) count that is not a multiple
@@ -702,7 +726,8 @@ def test_attention_dma_kernel(ops, b, sq, skv, heads, d):
     close(got, ref, tol=3e-3)
 
 
-@pytest.mark.parametrize("d,s,spike_at,gain", [(40, 1024, 900, 6.0), (80, 512, 70, 5.0), (40, 256, 255, 8.0), (80, 1024, 0, 6.0)])
+@pytest.mark.parametrize("d,s,spike_at,gain", [(40, 1024, 900, 6.0), (80, 512, 70, 5.0), (40, 256, 255, 8.0), (80, 1024, 0, 6.0), (160, 256, 200, 4.0),
+                                               (160, 128, 40, 4.0)])
 def test_attention_dma_reference_moves_late_and_peaked_rows(ops, d, s, spike_at, gain):
     """The rare branch of attn_dma_kernel: one key dominates every row from a LATER tile on (the reference moves there, O^T and the row
     sums are rescaled, the pending scores re-based), q / k / v as column slices of one fused buffer, queries scaled up so that the

@@ -1,0 +1,29 @@
+# Round-5 profile refresh, one gpurun call (run from the repo root on the GPU box).  Order matters: the PMC summaries (HBM traffic,
+# MFMA-busy) are collected first and copied to profiles/ so that the bench lines of the same call can carry them (bench.py reports them
+# only when their kernel-source hash matches the running build).  Everything lands in gpurun_out/r05_*; copy what should be judged into profiles/.
+export DTP_ROUND=r05
+export DTP_TUNE_CACHE=/tmp/tc.txt
+bash tools/pmc_unet.sh
+cp gpurun_out/r05_pmc_unet_traffic.json profiles/r05_pmc_unet_traffic.json
+bash tools/pmc_unet_mfma.sh > gpurun_out/r05_pmc_unet_mfma.log 2>&1
+cp gpurun_out/r05_pmc_unet_mfma.json profiles/r05_pmc_unet_mfma.json
+timeout 1500 python bench.py --dump-launches gpurun_out/r05_launches_b1.csv > gpurun_out/r05_b1.log 2>gpurun_out/r05_b1.err
+timeout 600 python bench.py --batch 8 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/r05_b8.log 2>gpurun_out/r05_b8.err
+timeout 600 python bench.py --res 256 --no-cpu-baseline --no-extras > gpurun_out/r05_256.log 2>gpurun_out/r05_256.err
+DTP_BENCH_BACKEND=gloo DTP_BENCH_SAME_DEVICE=1 timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-profile > gpurun_out/r05_gpus2_same_device.log 2>gpurun_out/r05_gpus2_same_device.err
+DTP_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-profile > gpurun_out/r05_rccl_one_rank.log 2>gpurun_out/r05_rccl_one_rank.err
+timeout 600 python bench.py --cpu-config0 > gpurun_out/r05_cpu_config0.json 2>gpurun_out/r05_cpu_config0.err
+DTP_FULLSIZE_JSON=gpurun_out/r05_fullsize_parity.json timeout 900 python -m pytest tests/test_gpu_fullsize.py -q -x -k test_config1_512_20steps_matches_cpu_oracle > gpurun_out/r05_fullsize_parity.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r05 -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-extras > /root/repo/gpurun_out/r05_prof.log 2>&1
+find /tmp/prof -name "*kernel_stats*" -exec cp {} /root/repo/gpurun_out/r05_kernel_stats.csv \;
+rm -rf /tmp/prof8
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof8 -o r05 -- python /root/repo/bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras > /root/repo/gpurun_out/r05_prof_b8.log 2>&1
+find /tmp/prof8 -name "*kernel_stats*" -exec cp {} /root/repo/gpurun_out/r05_kernel_stats_b8.csv \;
+if [ -f /tmp/tc.txt ]; then cp /tmp/tc.txt /root/repo/gpurun_out/r05_tune_cache.txt; else cp /root/repo/diffusiontexturepainting_amd/tune_seed.txt /root/repo/gpurun_out/r05_tune_cache.txt; fi
+cd /tmp && rm -rf /tmp/profm
+timeout 600 rocprofv3 --marker-trace --stats --output-format csv -d /tmp/profm -o r05 -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras > /root/repo/gpurun_out/r05_prof_marker.log 2>&1
+find /tmp/profm -name "*marker*stats*" -exec cp {} /root/repo/gpurun_out/r05_marker_stats.csv \;
+cd /root/repo
+for f in b1 b8 256; do grep "^{" gpurun_out/r05_$f.log | tail -1 | grep -o "\"ms_per_step\": [0-9.]*"; done
