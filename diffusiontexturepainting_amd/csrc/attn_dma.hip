@@ -520,7 +520,11 @@ int launch(const AttnParams& p, hipStream_t s) {
 
 // the LDS-DMA kernel takes the launch when every tile is a full 64-key tile and the 32-bit DMA offsets reach the whole sequence
 bool dtp_attention_dma_supported(const AttnParams& p) {
-  if (p.D != 40 && p.D != 80 && p.D != 160) return false;
+#ifdef DTP_EXPERIMENTAL  // d = 160 (levels 2-3, S = 256 / 64): parity-green, but the launches are ramp + one round trip and do not get faster
+  if (p.D != 40 && p.D != 80 && p.D != 160) return false;  // (20.0 -> 20.2 us at S = 256, 11.3 -> 13.3 us at S = 64 inside a stamp): not in the product build
+#else
+  if (p.D != 40 && p.D != 80) return false;
+#endif
   if (p.Skv < (p.D == 160 ? 64 : 128) || (p.Skv & 63) || p.Sq < 1) return false;
   if ((p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.ldo & 3)) return false;
   if (((uintptr_t)p.K & 15) || ((uintptr_t)p.V & 15) || ((uintptr_t)p.Q & 15) || ((uintptr_t)p.O & 7)) return false;
@@ -540,6 +544,8 @@ int dtp_launch_attention_dma(const AttnParams& p, hipStream_t s) {
   static const int nw8_env = [] { const char* e = getenv("DTP_ATTN_NW8"); return e ? atoi(e) : -1; }();
   const bool nw8 = nw8_env >= 0 ? nw8_env != 0 : (long long)((p.Sq + 255) / 256) * p.H * p.B >= 8LL * cus;
   if (p.D == 40) return nw8 ? launch<40, 4, 8>(p, s) : launch<40, 4, 4>(p, s);
-  if (p.D == 80) return launch<80, 3, 4>(p, s);
-  return launch<160, 3, 4>(p, s);  // levels 2-3 (S = 256 / 64): one 128-query workgroup per CU at most, the whole launch is latency
+#ifdef DTP_EXPERIMENTAL
+  if (p.D == 160) return launch<160, 3, 4>(p, s);  // levels 2-3 (S = 256 / 64): one 128-query workgroup per CU at most, the whole launch is latency
+#endif
+  return launch<80, 3, 4>(p, s);
 }

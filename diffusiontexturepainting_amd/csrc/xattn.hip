@@ -38,6 +38,9 @@ constexpr int XNS = 4;                          // phase-1 ring depth: three k-b
                                                 // every one of the C/64 k-blocks exposed: ~1 us each in a 20 us launch)
 constexpr int XLDS = XNS * XSTAGE + XW2 + XP + XBM * 8;
 
+// MULTI = false: exactly one column tile per workgroup (the round-4 kernel: with the tile loop around phase 2 its launches were 4-6 %
+// slower -- loop-carried epilogue operands, an extra wait and barrier); MULTI = true: XattnParams::ct tiles
+template <bool MULTI>
 __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;                       // [XNS][XSTAGE]; reused as the fp16 staging tile of both epilogues
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile_m = blockIdx.x, smp = blockIdx.z;
   const int ntiles = (p.C + XBN - 1) / XBN;
-  const int ct0 = blockIdx.y * p.ct, ct1 = min(ct0 + p.ct, ntiles);  // this workgroup's column tiles
+  const int ct0 = MULTI ? blockIdx.y * p.ct : blockIdx.y, ct1 = MULTI ? min(ct0 + p.ct, ntiles) : ct0 + 1;  // this workgroup's column tiles
   const int m0 = tile_m * XBM;
   int tile_n = ct0, n0 = ct0 * XBN;
   const f16* X = p.X + (size_t)smp * p.S * p.ldx;
@@ -251,14 +254,14 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
   // ---- per column tile: phase 2 (y3 tile = P W2^T over K = 128) + epilogue 2
   for (int ct = ct0; ct < ct1; ++ct) {
     char* const w2cur = ((ct - ct0) & 1) ? w2alt : w2s;
-    if (ct > ct0) {
+    if (MULTI && ct > ct0) {
       // this tile's W2 has landed (for every wave), and everyone has left the previous tile's staging tile and W2 buffer
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
     // the next tile: its W2 into the other buffer (last read one tile ago), its bias chunk and residual rows into registers -- all of it
     // lands under this tile's MFMAs and epilogue
-    const bool more = ct + 1 < ct1;
+    const bool more = MULTI && ct + 1 < ct1;
     float bvn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     f16x8 rvn[EIT];
     const int nn = (ct + 1) * XBN + nc * 8;
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
         }
       }
     }
+    if constexpr (!MULTI) break;
     // hand over to the next tile
     n = nn; col_ok = col_okn;
 #pragma unroll
@@ -330,7 +334,10 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
 
 }  // namespace
 
-void dtp_xattn_init() { (void)hipFuncSetAttribute((const void*)xattn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XLDS); }
+void dtp_xattn_init() {
+  (void)hipFuncSetAttribute((const void*)xattn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, XLDS);
+  (void)hipFuncSetAttribute((const void*)xattn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, XLDS);
+}
 
 bool dtp_xattn_supported(const XattnParams& p) {
   return p.C >= 64 && (p.C & 63) == 0 && (p.ldx & 7) == 0 && (p.ldy & 7) == 0 && (p.ldr & 7) == 0 && p.S >= 1 && p.N >= 1 && p.sm_valid >= 1 &&
@@ -354,6 +361,8 @@ int dtp_launch_xattn(const XattnParams& pin, hipStream_t s) {
   const int nt = (p.C + XBN - 1) / XBN;
   if (p.ct < 1) p.ct = dtp_xattn_tiles_per_wg(p.S, p.C, p.N);
   if (p.ct > nt) p.ct = nt;
-  hipLaunchKernelGGL(xattn_kernel, dim3((p.S + XBM - 1) / XBM, (nt + p.ct - 1) / p.ct, p.N), dim3(256), XLDS, s, p);
+  const dim3 grid((p.S + XBM - 1) / XBM, (nt + p.ct - 1) / p.ct, p.N);
+  if (p.ct > 1) hipLaunchKernelGGL(xattn_kernel<true>, grid, dim3(256), XLDS, s, p);
+  else hipLaunchKernelGGL(xattn_kernel<false>, grid, dim3(256), XLDS, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
