@@ -192,8 +192,13 @@ int dtp_op_reduce_groupnorm(const float* part, int splits, const float* bias, co
   if (rc) return rc;
   rc = ops_ws(dtp_groupnorm_ws_bytes(B, HW, C, groups));
   if (rc) return rc;
-  return dtp_launch_reduce_groupnorm(part, splits, (long long)B * HW * C, C, bias, (const f16*)resid, C, (f16*)conv_out, C, (f16*)y, C, gamma, beta, B, HW, C,
-                                     groups, eps, silu, g_ops.ws, (hipStream_t)s);
+  // $DTP_RGN_CX = Cx (read per call, parity tests only): the slabs hold the FIRST Cx channels ([splits][B*HW][Cx]); channels >= Cx are already in
+  // conv_out (the other half of a zero-copy concatenation) -- the round-5 form of the launch (engine.hip Builder::claim_reduce)
+  int cx = C;
+  if (const char* e = getenv("DTP_RGN_CX")) cx = atoi(e);
+  if (cx <= 0 || cx > C) cx = C;
+  return dtp_launch_reduce_groupnorm(part, splits, (long long)B * HW * cx, cx, bias, (const f16*)resid, cx, (f16*)conv_out, C, (f16*)y, C, gamma, beta, B, HW, C,
+                                     groups, eps, silu, g_ops.ws, (hipStream_t)s, cx);
 }
 
 int dtp_op_gn_fold_weights(const void* x, const void* W, int ldw, const float* bias, const float* gamma, const float* beta, int B, int HW, int C,

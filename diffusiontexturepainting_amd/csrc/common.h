@@ -52,9 +52,20 @@ static __device__ __forceinline__ void wait_lds_frags(f16x8 (&f)[NF]) {
 
 // exact (erf) GELU.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 output): one v_rcp, one v_exp and
 // a degree-5 Horner chain instead of the ~3x longer libm erff, which showed up in the GEGLU epilogues (2.6 G evaluations / stamp)
+// 1 / x by v_rcp_f32 alone (1 ulp).  `1.0f / x` and __frcp_rn are the correctly rounded division: v_div_scale x 2, v_rcp, four FMAs,
+// v_div_fmas, v_div_fixup -- ten VALU instructions per element, a third of the GEGLU epilogue of lnlin_kernel before round 5 noticed.
+#ifndef DTP_IEEE_DIV
+static __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#else  // (A/B builds only: tools/ab_build.sh)
+static __device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
+#endif
+// x * sigmoid(x) (x -> -inf: exp overflows to inf, rcp gives 0, the product -0 like the division's)
+static __device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.0f + __expf(-x)); }
+static __device__ __forceinline__ float quick_gelu_f(float x) { return x * fast_rcp(1.0f + __expf(-1.702f * x)); }
+
 static __device__ __forceinline__ float gelu_erf(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float t = fast_rcp(fmaf(0.3275911f, z, 1.0f));
   float pl = fmaf(1.061405429f, t, -1.453152027f);
   pl = fmaf(pl, t, 1.421413741f);
   pl = fmaf(pl, t, -0.284496736f);
@@ -212,7 +223,7 @@ int dtp_launch_groupnorm_apply(const f16* x, int ldx, f16* y, int ldy, const flo
 bool dtp_reduce_groupnorm_supported(int HW, int C, int groups);
 int dtp_launch_reduce_groupnorm(const float* part, int splits, long long slab, int ldp, const float* bias, const f16* R, int ldr,
                                 f16* c_out, int ldc, f16* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
-                                int groups, float eps, int silu, float* stats_ws, hipStream_t s);
+                                int groups, float eps, int silu, float* stats_ws, hipStream_t s, int Cx = 0);  // Cx: channels [0, Cx) from the slabs, the rest (a concatenation's other half) already in c_out; 0 = all
 // the split-K slabs of the conv that produced a GroupNorm's input (its reduce rides in the statistics pass)
 struct GnReduceSrc {
   const float* part; int splits; long long slab; int ldp; const float* bias; const f16* R; int ldr;

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float f = fmaf((float)v[e], ab[2 * e], ab[2 * e + 1]);
-            if (silu) f = f / (1.0f + __expf(-f));
+            if (silu) f = silu_f(f);
             o[e] = (f16)f;
           }
           *q = o;

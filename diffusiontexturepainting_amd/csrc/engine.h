@@ -331,7 +331,7 @@ struct Builder {
   T alloc(int B, int H, int W, int C);
   void release(const T& t);
   int gn(const T& x, const NormW& n, float eps, bool silu, T& y);
-  bool claim_reduce(const T& x, GemmParams& gp, int& bias_step_off);
+  bool claim_reduce(const T& x, GemmParams& gp, int& bias_step_off, bool allow_concat = false);
   bool claim_stats(const T& x, float** partials, int* nchunk);
   bool gn_linear_supported(const T& x, const ConvW& w) const;
   int gn_linear(const T& x, const NormW& n, float eps, const ConvW& w, T& y, RowStats* emit);

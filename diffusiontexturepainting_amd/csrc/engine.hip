@@ -365,10 +365,14 @@ void Builder::release(const T& t) { ctx_pool_put(c, t.p); }
 
 // The producer of x was a split-K conv whose reduce has not run yet: take the reduce over (the GroupNorm-side kernel sums the slabs
 // and writes x itself).  Re-pushes the conv with GF_NOREDUCE and returns its parameters.
-bool Builder::claim_reduce(const T& x, GemmParams& gp, int& bias_step_off) {
+bool Builder::claim_reduce(const T& x, GemmParams& gp, int& bias_step_off, bool allow_concat) {
   const LastGemm lg = prog->last_gemm;
   const int keep = GF_BIAS | GF_RESID | GF_CONV3 | GF_UPS2 | GF_MFAST;
-  if (!(c->fuse_reduce_gn && lg.valid && lg.p.splits > 1 && (f16*)lg.p.C == x.p && lg.p.ldc == x.ld && lg.p.M == (int)x.rows() && lg.p.N == x.C &&
+  // round 5 (allow_concat): x may be a zero-copy concatenation [producer's N channels | skip] -- the split producer wrote (will write) the
+  // FIRST lg.p.N channels of x's rows; the single-launch reduce + GroupNorm sums those from the slabs and reads the rest from x itself
+  const bool whole = lg.p.N == x.C;
+  const bool front = allow_concat && lg.p.N < x.C && (lg.p.N & 7) == 0 && x.H * x.W <= 256 && dtp_reduce_groupnorm_supported(x.H * x.W, x.C, 32);
+  if (!(c->fuse_reduce_gn && lg.valid && lg.p.splits > 1 && (f16*)lg.p.C == x.p && lg.p.ldc == x.ld && lg.p.M == (int)x.rows() && (whole || front) &&
         !(lg.p.flags & ~keep) && lg.p.batch <= 1 && (x.C & 7) == 0))
     return false;
   {  // what the GroupNorm-side reduce kernels accept (norm.hip): checked here, where the separate reduce is still the fallback
@@ -431,15 +435,33 @@ bool Builder::claim_stats(const T& x, float** partials, int* nchunk) {
 }
 
 int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
-  y = alloc(x.B, x.H, x.W, x.C);
-  if (!y.p) return DTP_ERR_HIP;
   Ctx* cc = c;
+  GemmParams gp;
+  int bso = -1;
+  static const bool concat_off = [] { const char* e = getenv("DTP_NO_REDUCE_IN_CONCAT_GN"); return e && e[0] && e[0] != '0'; }();  // A/B
+  const bool claimed = claim_reduce(x, gp, bso, !concat_off);
+  // The claimed reduce adds the producer's residual INSIDE the GroupNorm launch -- and that residual (a transformer block's input) is
+  // normally back in the pool by now, so the pool may hand its block out for y: one workgroup would write y where another still reads
+  // the residual.  (With y laid out exactly like the residual every thread reads the element it later overwrites, which is why the
+  // whole-tensor case never showed it; over a concatenation the pitches differ and the stamp stopped being reproducible.)  Blocks
+  // that overlap the residual are set aside while y is taken.
+  {
+    std::vector<void*> aside;
+    const char* r0 = (claimed && (gp.flags & GF_RESID)) ? (const char*)gp.R : nullptr;
+    const size_t rbytes = r0 ? (size_t)gp.M * gp.ldr * sizeof(f16) : 0, ybytes = (size_t)x.B * x.H * x.W * x.C * sizeof(f16);
+    for (int attempt = 0; attempt < 6; ++attempt) {
+      y = alloc(x.B, x.H, x.W, x.C);
+      if (!y.p || !r0 || !((const char*)y.p < r0 + rbytes && r0 < (const char*)y.p + ybytes)) break;
+      aside.push_back(y.p);
+      y.p = nullptr;
+    }
+    for (void* q : aside) ctx_pool_put(cc, q);
+    if (!y.p) { dtp_set_error("gn: no output block clear of the claimed reduce's residual"); return DTP_ERR_HIP; }
+  }
   cc->ws_need = std::max(cc->ws_need, dtp_groupnorm_ws_bytes(x.B, x.H * x.W, x.C, 32));
   const T xx = x, yy = y;
   const NormW nn = n;
-  GemmParams gp;
-  int bso = -1;
-  if (claim_reduce(x, gp, bso)) {
+  if (claimed) {
     const bool has_bias = (gp.flags & GF_BIAS) != 0;
     // small maps: one launch does it all; large maps: the reduce rides in the statistics pass, whose partial sums live behind the slabs
     const size_t slab_bytes = (dtp_gemm_workspace_bytes(gp) + 255) & ~(size_t)255;
@@ -448,8 +470,8 @@ int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
       const float* bias = !has_bias ? nullptr : (bso >= 0 ? cc->temb_table + (size_t)step * cc->unet.temb_total + bso : gp.bias);
       return dtp_launch_reduce_groupnorm(cc->ws, gp.splits, (long long)gp.M * gp.N, gp.N, bias, (gp.flags & GF_RESID) ? gp.R : nullptr, gp.ldr,
                                          xx.p, xx.ld, yy.p, yy.ld, nn.g, nn.b, xx.B, xx.H * xx.W, xx.C, 32, eps, silu ? 1 : 0,
-                                         (float*)((char*)cc->ws + slab_bytes), s);
-    }, "reduce+gn B=" + std::to_string(x.B) + " HW=" + std::to_string(x.H * x.W) + " C=" + std::to_string(x.C) + " splits=" + std::to_string(gp.splits));
+                                         (float*)((char*)cc->ws + slab_bytes), s, gp.N);
+    }, std::string(gp.N < x.C ? "reduce(front " + std::to_string(gp.N) + ")+gn B=" : "reduce+gn B=") + std::to_string(x.B) + " HW=" + std::to_string(x.H * x.W) + " C=" + std::to_string(x.C) + " splits=" + std::to_string(gp.splits));
     return DTP_OK;
   }
   float* partials = nullptr;

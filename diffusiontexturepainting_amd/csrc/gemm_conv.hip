@@ -573,11 +573,11 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
       }
       if (fl & GF_QUICKGELU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = x[e] / (1.0f + __expf(-1.702f * x[e]));
+        for (int e = 0; e < 8; ++e) x[e] = quick_gelu_f(x[e]);
       }
       if (fl & GF_SILU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = x[e] / (1.0f + __expf(-x[e]));
+        for (int e = 0; e < 8; ++e) x[e] = silu_f(x[e]);
       }
       if (fl & GF_SOFTMAX16) {  // a group = two adjacent 8-column chunks = this lane and lane ^ 1 (N % 16 == 0: both active)
         const int half = (nc & 1) * 8;
@@ -680,8 +680,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
       else if (fl & GF_BIAS) x[e] += p.bias[n + e];
       if (fl & GF_BIAS_M) x[e] += p.bias[m];
       if (fl & GF_GELU) x[e] = gelu_erf(x[e]);
-      if (fl & GF_QUICKGELU) x[e] = x[e] / (1.0f + __expf(-1.702f * x[e]));
-      if (fl & GF_SILU) x[e] = x[e] / (1.0f + __expf(-x[e]));
+      if (fl & GF_QUICKGELU) x[e] = quick_gelu_f(x[e]);
+      if (fl & GF_SILU) x[e] = silu_f(x[e]);
     }
     if constexpr (VEC) {
 #pragma unroll

@@ -392,11 +392,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_wide_kernel(const GemmParams
         }
         if (fl & GF_QUICKGELU) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) x[k] = x[k] / (1.0f + __expf(-1.702f * x[k]));
+          for (int k = 0; k < 8; ++k) x[k] = quick_gelu_f(x[k]);
         }
         if (fl & GF_SILU) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) x[k] = x[k] / (1.0f + __expf(-x[k]));
+          for (int k = 0; k < 8; ++k) x[k] = silu_f(x[k]);
         }
         if (fl & GF_RESID) {  // active implies col_ok, i.e. pre_r: the row was prefetched
 #pragma unroll

@@ -166,6 +166,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
   auto w_piece = [&](int uu, int kb) {  // piece kb of unit uu: rows wave*8.. of the 32, k-block kb of the unit's 320 k
     const int soff = (unit_row0(uu) * p.ldw + (uu % KU) * 320 + kb * 64) * 2;
     const int vo = voffW;
+#ifdef DTP_LNLIN_NO_DMA  // (diagnostic builds only: the first two units are loaded, nothing after them)
+    if (uu >= 2) return;
+#endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(ring + (uu % 3) * UNIT_BYTES + kb * 4096 + wave * 1024), 16, vo, soff, 0, 0);
   };
 #pragma unroll
@@ -190,7 +193,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
   auto unit = [&](auto selc, auto partc) {
     constexpr int SEL = decltype(selc)::value, PART = decltype(partc)::value;
     if (u + 1 < nunits) wait_vmcnt<5>(); else wait_vmcnt<0>();
+#ifndef DTP_LNLIN_NO_BARRIER
     __builtin_amdgcn_s_barrier();  // unit u is complete in LDS; every wave has left unit u - 1: its slot takes unit u + 2
+#endif
     const bool more = u + 2 < nunits;
     const uint32_t sb = slot * UNIT_BYTES;
     uint32_t xs[4];
@@ -249,6 +254,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
       unit(I1{}, I0{});
       if constexpr (KU == 2) unit(I1{}, I1{});
     }
+#ifdef DTP_LNLIN_NO_EPI  // (diagnostic builds only)
+    asm volatile("" :: "v"(acc_a), "v"(acc_g));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_a[r] = 0.f; acc_g[r] = 0.f; }
+#else
     {  // ---- the chunk is complete: epilogue of 32 columns x this wave's 32 rows
       const int c = c0 + cl;
       const float* v = vecs + cl * 128;
@@ -302,9 +312,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
             rs1[rr] += s1; rs2[rr] += s2;
           }
         }
+#ifndef DTP_LNLIN_NO_STORE
         if (m < Mtot) *(f16x8*)((f16*)p.C + (size_t)m * p.ldc + ncol + cc * 8) = ov;
+#else
+        if (m < 0) *(f16x8*)((f16*)p.C + (size_t)m * p.ldc + ncol + cc * 8) = ov;
+#endif
       }
     }
+#endif
   }
   if constexpr (!LN) {
     if ((p.flags & GF_ROWSTATS) && (lane & 3) == 0) {  // one partial per column range: st_out [range][st_rows][2]
@@ -338,6 +353,16 @@ void dtp_lnlin_init() {
   (void)hipFuncSetAttribute((const void*)lnlin_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
   (void)hipFuncSetAttribute((const void*)lnlin_kernel<1, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
   (void)hipFuncSetAttribute((const void*)lnlin_kernel<2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
+}
+
+// diagnostic (tools/scratch, not in include/dtp.h): workgroups of one instantiation the runtime will keep resident per CU
+extern "C" int dtp_debug_lnlin_occupancy(int ku, int geglu, int ln) {
+  int n = -1;
+  const void* f = ln ? (ku == 1 ? (geglu ? (const void*)lnlin_kernel<1, true> : (const void*)lnlin_kernel<1, false>)
+                                : (geglu ? (const void*)lnlin_kernel<2, true> : (const void*)lnlin_kernel<2, false>))
+                     : (ku == 1 ? (const void*)lnlin_kernel<1, false, false> : (const void*)lnlin_kernel<2, false, false>);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, LNLIN_LDS) != hipSuccess) return -1;
+  return n;
 }
 
 // Dense, K = 320 or 640, fp16 output.  Either LayerNorm-folded (GF_LNFOLD: in-kernel statistics, st_in is not needed and ignored;

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const f16* __restrict__ 
       const float gm = e < 4 ? ga[e] : gb[e - 4], bt = e < 4 ? ba[e] : bb[e - 4];
       const bool first = e < split;
       float f = ((float)v[e] - (first ? m0 : m1)) * (first ? r0 : r1) * gm + bt;
-      if (silu) f = f / (1.0f + __expf(-f));
+      if (silu) f = silu_f(f);
       o[e] = (f16)f;
     }
     *(f16x8*)(yb + (size_t)pix * ldy + c0) = o;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const f16* __restrict__ 
       const bool first = e < split;
       const float gm = e < 4 ? ga0[e] : ga1[e - 4], bt = e < 4 ? be0[e] : be1[e - 4];
       float f = ((float)v[e] - (first ? m0 : m1)) * (first ? r0 : r1) * gm + bt;
-      if (silu) f = f / (1.0f + __expf(-f));
+      if (silu) f = silu_f(f);
       o[e] = (f16)f;
     }
     *(f16x8*)(yb + (size_t)pix * ldy + c0) = o;
@@ -316,7 +316,9 @@ __global__ __launch_bounds__(1024) void gn_reduce_fused_kernel(const float* __re
                                                                const float* __restrict__ bias, const f16* __restrict__ R, int ldr,
                                                                f16* __restrict__ c_out, int ldc, f16* __restrict__ y, int ldy,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, int HW,
-                                                               int cpg, int silu, float inv_count, float eps) {
+                                                               int cpg, int silu, float inv_count, float eps, int Cx) {
+  // Cx: channels [0, Cx) come from the slabs (and are written to c_out); channels >= Cx are already in c_out -- the other half of a
+  // zero-copy concatenation whose first half the split conv produced (round 5: its reduce used to be a launch of its own)
   __shared__ float red[16][2 * G];
   __shared__ float st[2 * G];
   const int nthr = blockDim.x, nwave = blockDim.x >> 6;
@@ -334,21 +336,25 @@ __global__ __launch_bounds__(1024) void gn_reduce_fused_kernel(const float* __re
     if (i < total) {
       const int pix = i / nchs, c0 = (i - pix * nchs) * 8;
       const size_t row = (size_t)b * HW + pix;
-      f32x4 a0, a1;
-      slab_sum8(part + row * ldp + cs + c0, splits, slab, a0, a1);
-      if (bias) {
-        const f32x4 b0 = *(const f32x4*)(bias + cs + c0), b1 = *(const f32x4*)(bias + cs + c0 + 4);
-        a0 += b0; a1 += b1;
-      }
-      if (R) {
-        const f16x8 r = *(const f16x8*)(R + row * ldr + cs + c0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { a0[e] += (float)r[e]; a1[e] += (float)r[4 + e]; }
-      }
       f16x8 h;
+      if (cs + c0 < Cx) {
+        f32x4 a0, a1;
+        slab_sum8(part + row * ldp + cs + c0, splits, slab, a0, a1);
+        if (bias) {
+          const f32x4 b0 = *(const f32x4*)(bias + cs + c0), b1 = *(const f32x4*)(bias + cs + c0 + 4);
+          a0 += b0; a1 += b1;
+        }
+        if (R) {
+          const f16x8 r = *(const f16x8*)(R + row * ldr + cs + c0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { h[e] = (f16)a0[e]; h[4 + e] = (f16)a1[e]; }
-      *(f16x8*)(c_out + row * ldc + cs + c0) = h;
+          for (int e = 0; e < 4; ++e) { a0[e] += (float)r[e]; a1[e] += (float)r[4 + e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = (f16)a0[e]; h[4 + e] = (f16)a1[e]; }
+        *(f16x8*)(c_out + row * ldc + cs + c0) = h;
+      } else {
+        h = *(const f16x8*)(c_out + row * ldc + cs + c0);
+      }
       val[k] = h;
       const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
       float u0 = 0.f, w0 = 0.f, u1 = 0.f, w1 = 0.f;
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(1024) void gn_reduce_fused_kernel(const float* __re
         const bool first = e < split;
         const float gm = e < 4 ? ga0[e] : ga1[e - 4], bt = e < 4 ? be0[e] : be1[e - 4];
         float f = ((float)v[e] - (first ? m0 : m1)) * (first ? r0 : r1) * gm + bt;
-        if (silu) f = f / (1.0f + __expf(-f));
+        if (silu) f = silu_f(f);
         o[e] = (f16)f;
       }
       *(f16x8*)(y + ((size_t)b * HW + pix) * ldy + cs + c0) = o;
@@ -715,7 +721,12 @@ bool dtp_reduce_groupnorm_supported(int HW, int C, int groups) {
 
 int dtp_launch_reduce_groupnorm(const float* part, int splits, long long slab, int ldp, const float* bias, const f16* R, int ldr,
                                 f16* c_out, int ldc, f16* y, int ldy, const float* gamma, const float* beta, int B, int HW, int C,
-                                int groups, float eps, int silu, float* stats_ws, hipStream_t s) {
+                                int groups, float eps, int silu, float* stats_ws, hipStream_t s, int Cx) {
+  if (Cx <= 0 || Cx > C) Cx = C;
+  if (Cx < C && ((Cx & 7) || !dtp_reduce_groupnorm_supported(HW, C, groups))) {
+    dtp_set_error("reduce+groupnorm over a concatenation: HW=%d C=%d Cx=%d unsupported (single-launch shapes only)", HW, C, Cx);
+    return DTP_ERR_ARG;
+  }
   if ((ldp & 3) || (ldc & 7) || (ldy & 7) || (R && (ldr & 7)) || (C & 7) || (C % groups) || groups > 64 || C / groups < 4 ||
       (C / groups < 8 && C / groups != 4)) {
     dtp_set_error("reduce+groupnorm: HW=%d C=%d groups=%d unsupported", HW, C, groups);
@@ -730,7 +741,7 @@ int dtp_launch_reduce_groupnorm(const float* part, int splits, long long slab, i
 #else
   constexpr bool small_fused = true;
 #endif
-  if (!dtp_reduce_groupnorm_supported(HW, C, groups) || (!small_fused && stats_ws && HW >= 32)) {  // reduce folded into the statistics pass, then the apply pass
+  if (Cx == C && (!dtp_reduce_groupnorm_supported(HW, C, groups) || (!small_fused && stats_ws && HW >= 32))) {  // reduce folded into the statistics pass, then the apply pass
     if (!stats_ws) { dtp_set_error("reduce+groupnorm: the two-pass form needs the statistics workspace"); return DTP_ERR_ARG; }
     const GnReduceSrc rd = {part, splits, slab, ldp, bias, R, ldr};
     return groupnorm_two_pass(c_out, ldc, y, ldy, gamma, beta, stats_ws, B, HW, C, groups, eps, silu, &rd, s);
@@ -742,7 +753,7 @@ int dtp_launch_reduce_groupnorm(const float* part, int splits, long long slab, i
   dim3 grid(groups / G, B);
   const int items = HW * ((G * cpg) >> 3);
   const dim3 blk(items >= 1024 ? 1024 : (items >= 512 ? 512 : 256));
-#define DTP_RGN(GG) hipLaunchKernelGGL((gn_reduce_fused_kernel<GG, 4>), grid, blk, 0, s, part, splits, slab, ldp, bias, R, ldr, c_out, ldc, y, ldy, gamma, beta, HW, cpg, silu, inv, eps)
+#define DTP_RGN(GG) hipLaunchKernelGGL((gn_reduce_fused_kernel<GG, 4>), grid, blk, 0, s, part, splits, slab, ldp, bias, R, ldr, c_out, ldc, y, ldy, gamma, beta, HW, cpg, silu, inv, eps, Cx)
   if (G == 1) DTP_RGN(1); else if (G == 2) DTP_RGN(2); else DTP_RGN(4);
 #undef DTP_RGN
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;

@@ -114,6 +114,14 @@ static int vae_attention(Builder& b, const T& x, const VaeAttnW& w, T& out) {
   return DTP_OK;
 }
 
+// largest sub-batch whose [Bc][R][R][Cmax] f16 tensor stays below the 2 GiB the buffer descriptors of the GEMM / conv kernels span
+static int vae_sub_batch(int B, int R, int Cmax) {
+  const long long per = (long long)R * R * Cmax * 2;
+  const int cap = (int)std::max(1LL, ((1LL << 31) - 1) / per);
+  const int n = (B + cap - 1) / cap;  // number of sub-batches; spread evenly so they share their tuned tiles
+  return (B + n - 1) / n;
+}
+
 int build_vae_enc_prog(Ctx* c, int B, VaeEncProg& pr) {
   const VaeW& v = c->vae;
   const int R = c->R;
@@ -122,8 +130,13 @@ int build_vae_enc_prog(Ctx* c, int B, VaeEncProg& pr) {
   RC(ctx_persistent(c, (size_t)B * R * R * 8 * 2, &p, true)); pr.in8 = (f16*)p;
   RC(ctx_persistent(c, (size_t)B * c->h * c->h * 8 * 4, &p, true)); pr.moments = (float*)p;
   Builder b{c, &pr.main};
+  // the kernels address an operand by 32-bit byte offsets into a 2 GiB descriptor: a batch whose widest full-resolution tensor
+  // (128 channels here) would reach that is run as sub-batches, one after the other, in the same program
+  const int Bc = vae_sub_batch(B, R, 128);
+  for (int b0 = 0; b0 < B; b0 += Bc) {
+  const int Bn = std::min(Bc, B - b0);
   T x0;
-  x0.p = pr.in8; x0.B = B; x0.H = R; x0.W = R; x0.C = 8; x0.ld = 8;
+  x0.p = pr.in8 + (size_t)b0 * R * R * 8; x0.B = Bn; x0.H = R; x0.W = R; x0.C = 8; x0.ld = 8;
   T x;
   RC(b.conv3(x0, v.enc_in, 1, 1, false, R, R, nullptr, -1, x));
   for (int i = 0; i < 4; ++i) {
@@ -146,8 +159,9 @@ int build_vae_enc_prog(Ctx* c, int B, VaeEncProg& pr) {
   RC(b.resnet(z, v.enc_mid[1], 1e-6f, false, w2)); b.release(z);
   RC(b.gn(w2, v.enc_norm_out, 1e-6f, true, t)); b.release(w2);
   T o;
-  RC(b.conv3(t, v.enc_out, 1, 1, false, c->h, c->h, nullptr, -1, o, GF_OUT_F32, pr.moments, 8));
+  RC(b.conv3(t, v.enc_out, 1, 1, false, c->h, c->h, nullptr, -1, o, GF_OUT_F32, pr.moments + (size_t)b0 * c->h * c->h * 8, 8));
   b.release(t);
+  }
   tune_cache_save(c);
   return ensure_ws(c);
 }
@@ -160,8 +174,11 @@ int build_vae_dec_prog(Ctx* c, int B, VaeDecProg& pr) {
   RC(ctx_persistent(c, (size_t)B * h * h * 8 * 2, &p, true)); pr.in8 = (f16*)p;
   RC(ctx_persistent(c, (size_t)B * R * R * 4 * 4, &p, true)); pr.out32 = (float*)p;
   Builder b{c, &pr.main};
+  const int Bc = vae_sub_batch(B, R, 256);  // (see build_vae_enc_prog; 256 channels at full resolution after the last upsampling)
+  for (int b0 = 0; b0 < B; b0 += Bc) {
+  const int Bn = std::min(Bc, B - b0);
   T x0;
-  x0.p = pr.in8; x0.B = B; x0.H = h; x0.W = h; x0.C = 8; x0.ld = 8;
+  x0.p = pr.in8 + (size_t)b0 * h * h * 8; x0.B = Bn; x0.H = h; x0.W = h; x0.C = 8; x0.ld = 8;
   T x, y, z, w2;
   RC(b.conv3(x0, v.dec_in, 1, 1, false, h, h, nullptr, -1, x));
   RC(b.resnet(x, v.dec_mid[0], 1e-6f, false, y)); b.release(x);
@@ -184,8 +201,9 @@ int build_vae_dec_prog(Ctx* c, int B, VaeDecProg& pr) {
   }
   T t, o;
   RC(b.gn(x, v.dec_norm_out, 1e-6f, true, t)); b.release(x);
-  RC(b.conv3(t, v.dec_out, 1, 1, false, R, R, nullptr, -1, o, GF_OUT_F32, pr.out32, 4));
+  RC(b.conv3(t, v.dec_out, 1, 1, false, R, R, nullptr, -1, o, GF_OUT_F32, pr.out32 + (size_t)b0 * R * R * 4, 4));
   b.release(t);
+  }
   tune_cache_save(c);
   return ensure_ws(c);
 }

@@ -196,13 +196,29 @@ def groupnorm_apply(x, gamma, beta, partial, groups=32, eps=1e-5, silu=False):
     return y
 
 
-def reduce_groupnorm(part, gamma, beta, bias=None, resid=None, groups=32, eps=1e-5, silu=False):
-    """part f32 [splits, B, HW, C] split-K slabs of a conv -> (conv output f16 [B,HW,C], GroupNorm(+SiLU) of it)."""
+def reduce_groupnorm(part, gamma, beta, bias=None, resid=None, groups=32, eps=1e-5, silu=False, skip=None):
+    """part f32 [splits, B, HW, Cx] split-K slabs of a conv -> (conv output f16 [B,HW,C], GroupNorm(+SiLU) of it).
+    skip f16 [B, HW, C - Cx] (optional): the tensor is the zero-copy concatenation [conv output | skip]; the slabs (bias, residual) cover its
+    first Cx channels only and the GroupNorm runs over all C = Cx + skip channels."""
     lib = _lib.load()
-    sp, b, hw, c = part.shape
+    sp, b, hw, cx = part.shape
+    c = cx + (skip.shape[-1] if skip is not None else 0)
     out, y = torch.empty(b, hw, c, dtype=torch.float16, device=part.device), torch.empty(b, hw, c, dtype=torch.float16, device=part.device)
-    check(lib.dtp_op_reduce_groupnorm(ptr(part), sp, ptr(bias), ptr(resid), ptr(out), ptr(y), ptr(gamma), ptr(beta), b, hw, c, groups, eps, int(silu),
-                                      _stream()), "reduce_groupnorm")
+    import os
+    old = os.environ.get("DTP_RGN_CX")
+    try:
+        if skip is not None:
+            out[..., cx:] = skip
+            os.environ["DTP_RGN_CX"] = str(cx)  # (read per call by dtp_op_reduce_groupnorm: the C ABI keeps its round-2 signature)
+        else:
+            os.environ.pop("DTP_RGN_CX", None)
+        check(lib.dtp_op_reduce_groupnorm(ptr(part), sp, ptr(bias), ptr(resid), ptr(out), ptr(y), ptr(gamma), ptr(beta), b, hw, c, groups, eps, int(silu),
+                                          _stream()), "reduce_groupnorm")
+    finally:
+        if old is None:
+            os.environ.pop("DTP_RGN_CX", None)
+        else:
+            os.environ["DTP_RGN_CX"] = old
     return out, y
 
 

@@ -112,8 +112,11 @@ def test_stamp_vs_oracle(env, b, steps, tg_steps, tg, pad):
     assert err <= 1e-2
     assert m.stamp_info()["unet_evals"] == steps - 1
     # replay (graph path) must be bit-identical to the first (capturing) run
-    again = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
-    assert torch.equal(again, got)
+    # (three replays: a race between two workgroups of one launch -- round 5: a GroupNorm output placed over the residual its claimed
+    # split-K reduce still read -- shows up as run-to-run differences, not necessarily in the first pair)
+    for _ in range(3):
+        again = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
+        assert torch.equal(again, got)
     comp = m.generate(canvas, latents=lat, vae_eps=eps, **st)
     assert (comp.cpu() - pipeline.composite(canvas, ref)).abs().max().item() <= 1e-2
     a = canvas[:, 3:]

@@ -639,6 +639,35 @@ def test_reduce_groupnorm(ops, b, hw, c, splits, silu, bias, resid):
     close(y, ref)
 
 
+@pytest.mark.parametrize("b,hw,cx,cskip,splits,bias,resid", [(3, 64, 1280, 1280, 5, True, True), (3, 256, 1280, 640, 4, True, False), (2, 256, 1280, 1280, 2, False, True),
+                                                             (3, 16, 1280, 1280, 12, True, True), (1, 64, 640, 320, 3, True, False)])
+def test_reduce_groupnorm_over_a_concatenation(ops, b, hw, cx, cskip, splits, bias, resid):
+    """Round 5: the GroupNorm that opens an up-block ResBlock runs over the zero-copy concatenation [x | skip]; when x's producer was a
+    split conv / Linear its reduce now rides in that GroupNorm (it used to be a launch of its own): the first Cx channels are summed from
+    the slabs (+ bias, + residual) and written back BIT-exactly, the skip half is read in place, groups may straddle the seam
+    (1280 + 640 channels: 60 per group)."""
+    g = torch.Generator().manual_seed(145)
+    c = cx + cskip
+    part = torch.randn(splits, b, hw, cx, generator=g) * 0.7
+    bv = torch.randn(cx, generator=g) if bias else None
+    rv = rnd(b, hw, cx, seed=146) if resid else None
+    skip = (rnd(b, hw, cskip, seed=147).float() * 1.3 + 0.2).half()
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    acc = part[0].clone()
+    for z in range(1, splits):
+        acc += part[z]
+    if bias:
+        acc += bv
+    if resid:
+        acc += rv.float()
+    cat = torch.cat([acc.half(), skip], dim=-1)
+    ref = F.silu(F.group_norm(cat.float().permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1))
+    out, y = ops.reduce_groupnorm(part.cuda(), gamma.cuda(), beta.cuda(), bias=bv.cuda() if bias else None, resid=rv.cuda() if resid else None, silu=True,
+                                  skip=skip.cuda())
+    assert torch.equal(out.cpu(), cat)
+    close(y, ref)
+
+
 @pytest.mark.parametrize("b,hw,c,n", [(3, 4096, 320, 320), (2, 1024, 640, 640), (1, 1024, 1280, 1280), (2, 1600, 960, 320)])
 def test_groupnorm_folded_into_linear(ops, b, hw, c, n):
     """proj_in(GroupNorm(x)) as a grouped GEMM on the RAW x with per-sample weights W diag(gamma rstd_b) and biases b + W (beta - mean_b
