@@ -50,8 +50,6 @@ static __device__ __forceinline__ void wait_lds_frags(f16x8 (&f)[NF]) {
 
 
 
-// exact (erf) GELU.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 output): one v_rcp, one v_exp and
-// a degree-5 Horner chain instead of the ~3x longer libm erff, which showed up in the GEGLU epilogues (2.6 G evaluations / stamp)
 // 1 / x by v_rcp_f32 alone (1 ulp).  `1.0f / x` and __frcp_rn are the correctly rounded division: v_div_scale x 2, v_rcp, four FMAs,
 // v_div_fmas, v_div_fixup -- ten VALU instructions per element, a third of the GEGLU epilogue of lnlin_kernel before round 5 noticed.
 #ifndef DTP_IEEE_DIV
@@ -63,6 +61,9 @@ static __device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
 static __device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.0f + __expf(-x)); }
 static __device__ __forceinline__ float quick_gelu_f(float x) { return x * fast_rcp(1.0f + __expf(-1.702f * x)); }
 
+// exact (erf) GELU.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 output): one v_rcp, one v_exp and
+// a degree-5 Horner chain instead of the ~3x longer libm erff, which showed up in the GEGLU epilogues (2.6 G evaluations / stamp)
+#ifndef DTP_GELU_POLY
 static __device__ __forceinline__ float gelu_erf(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
   const float t = fast_rcp(fmaf(0.3275911f, z, 1.0f));
@@ -73,6 +74,25 @@ static __device__ __forceinline__ float gelu_erf(float x) {
   const float e = 1.0f - pl * t * __expf(-z * z);  // erf(|x| / sqrt 2)
   return 0.5f * x * (1.0f + copysignf(e, x));
 }
+#else
+// (A/B builds only: tools/ab_build.sh gelu_poly -DDTP_GELU_POLY.)  erf(z) = z P(z^2) on [0, 3], degree 8 in z^2 (minimax fit, |error| <=
+// 1.7e-5; z clamped at 3): no transcendental, 215 instead of 255 VALU instructions per lnlin chunk -- measured round 5: the GEGLU
+// launches -1 ... -3 %, the stamp within noise (profiles/r05_lnlin_ablation.txt); not worth 5e-5 of absolute error, not shipped.
+static __device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fminf(fabsf(x) * 0.70710678118654752f, 3.0f);
+  const float u = z * z;
+  float p = fmaf(4.074155537e-08f, u, -1.944803169e-06f);
+  p = fmaf(p, u, 4.106023957e-05f);
+  p = fmaf(p, u, -5.110346811e-04f);
+  p = fmaf(p, u, 4.235417930e-03f);
+  p = fmaf(p, u, -2.510283806e-02f);
+  p = fmaf(p, u, 1.110793054e-01f);
+  p = fmaf(p, u, -3.753148582e-01f);
+  p = fmaf(p, u, 1.128268424e+00f);
+  const float h = 0.5f * x;
+  return fmaf(fabsf(h), p * z, h);  // 0.5 x (1 + sign(x) erf(|x| / sqrt 2))
+}
+#endif
 
 // Sum n (value, value) pairs spaced `stride` floats apart, IN ORDER, with the loads issued eight at a time before their additions.
 // A `for (q) s += p[q * stride]` loop chains one memory round trip per term (hipcc does not pipeline a runtime trip count): with

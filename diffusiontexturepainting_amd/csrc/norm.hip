@@ -35,9 +35,25 @@ __device__ __forceinline__ void slab_sum8(const float* __restrict__ pp, int spli
     a0 += t4; a1 += t5;
     a0 += t6; a1 += t7;
   }
-  for (; z < splits; ++z) {
-    const f32x4 t0 = *(const f32x4*)(pp + (size_t)z * slab), t1 = *(const f32x4*)(pp + (size_t)z * slab + 4);
-    a0 += t0; a1 += t1;
+  // the last one to three slabs: loads first as well (a `for` over them was one round trip per slab: splits = 3 / 4 paid two / three)
+  const int rem = splits - z;
+  if (rem > 0) {
+    const float* q = pp + (size_t)z * slab;
+    const f32x4 t0 = *(const f32x4*)q, t1 = *(const f32x4*)(q + 4);
+    if (rem > 1) {
+      const f32x4 t2 = *(const f32x4*)(q + slab), t3 = *(const f32x4*)(q + slab + 4);
+      if (rem > 2) {
+        const f32x4 t4 = *(const f32x4*)(q + 2 * slab), t5 = *(const f32x4*)(q + 2 * slab + 4);
+        a0 += t0; a1 += t1;
+        a0 += t2; a1 += t3;
+        a0 += t4; a1 += t5;
+      } else {
+        a0 += t0; a1 += t1;
+        a0 += t2; a1 += t3;
+      }
+    } else {
+      a0 += t0; a1 += t1;
+    }
   }
 }
 
@@ -172,6 +188,22 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const f16* __restrict__ 
                                                         int groups, int silu, float inv_count, float eps) {
   __shared__ float st[64 * 2];
   const int b = blockIdx.y;
+  const int nch = C >> 3;
+  const long long total = (long long)HW * nch;
+  const f16* xb = x + (size_t)b * HW * ldx;
+  f16* yb = y + (size_t)b * HW * ldy;
+  // the first item's activations and affine parameters are requested BEFORE the partial sums are combined: behind the barrier they
+  // were a second dependent round trip of a launch that is two round trips long
+  const long long i_first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  f16x8 pv = {};
+  f32x4 pga = {0.f, 0.f, 0.f, 0.f}, pgb = pga, pba = pga, pbb = pga;
+  if (i_first < total) {
+    const long long pix = i_first / nch;
+    const int c0 = (int)(i_first - pix * nch) * 8;
+    pv = *(const f16x8*)(xb + (size_t)pix * ldx + c0);
+    pga = *(const f32x4*)(gamma + c0); pgb = *(const f32x4*)(gamma + c0 + 4);
+    pba = *(const f32x4*)(beta + c0); pbb = *(const f32x4*)(beta + c0 + 4);
+  }
   {
     const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
     float s = 0.f, q = 0.f;
@@ -202,17 +234,16 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const f16* __restrict__ 
     }
   }
   __syncthreads();
-  const int nch = C >> 3;
-  const long long total = (long long)HW * nch;
-  const f16* xb = x + (size_t)b * HW * ldx;
-  f16* yb = y + (size_t)b * HW * ldy;
-#pragma unroll 2
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = i_first; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long pix = i / nch;
     const int c0 = (int)(i - pix * nch) * 8;
-    const f16x8 v = *(const f16x8*)(xb + (size_t)pix * ldx + c0);
-    const f32x4 ga = *(const f32x4*)(gamma + c0), gb = *(const f32x4*)(gamma + c0 + 4);
-    const f32x4 ba = *(const f32x4*)(beta + c0), bb = *(const f32x4*)(beta + c0 + 4);
+    f16x8 v = pv;
+    f32x4 ga = pga, gb = pgb, ba = pba, bb = pbb;
+    if (i != i_first) {
+      v = *(const f16x8*)(xb + (size_t)pix * ldx + c0);
+      ga = *(const f32x4*)(gamma + c0); gb = *(const f32x4*)(gamma + c0 + 4);
+      ba = *(const f32x4*)(beta + c0); bb = *(const f32x4*)(beta + c0 + 4);
+    }
     const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
     const float m0 = st[g0 * 2], r0 = st[g0 * 2 + 1];
     const float m1 = st[(g0 + 1 < groups ? g0 + 1 : g0) * 2], r1 = st[(g0 + 1 < groups ? g0 + 1 : g0) * 2 + 1];
@@ -330,6 +361,7 @@ __global__ __launch_bounds__(1024) void gn_reduce_fused_kernel(const float* __re
 #pragma unroll
   for (int g = 0; g < G; ++g) s[g] = q[g] = 0.f;
   f16x8 val[MAXI];
+  f32x4 pga0 = {0.f, 0.f, 0.f, 0.f}, pga1 = pga0, pbe0 = pga0, pbe1 = pga0;  // gamma / beta of item k = 0
 #pragma unroll
   for (int k = 0; k < MAXI; ++k) {
     const int i = threadIdx.x + k * nthr;
@@ -338,14 +370,19 @@ __global__ __launch_bounds__(1024) void gn_reduce_fused_kernel(const float* __re
       const size_t row = (size_t)b * HW + pix;
       f16x8 h;
       if (cs + c0 < Cx) {
+        // bias and residual are requested BEFORE the slabs: behind the slab sums each was one more dependent round trip
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        f16x8 r = {};
+        if (bias) { b0 = *(const f32x4*)(bias + cs + c0); b1 = *(const f32x4*)(bias + cs + c0 + 4); }
+        if (R) r = *(const f16x8*)(R + row * ldr + cs + c0);
+        if (k == 0) {  // (and the affine parameters of the first item: they were a fourth round trip behind the second barrier)
+          pga0 = *(const f32x4*)(gamma + cs + c0); pga1 = *(const f32x4*)(gamma + cs + c0 + 4);
+          pbe0 = *(const f32x4*)(beta + cs + c0); pbe1 = *(const f32x4*)(beta + cs + c0 + 4);
+        }
         f32x4 a0, a1;
         slab_sum8(part + row * ldp + cs + c0, splits, slab, a0, a1);
-        if (bias) {
-          const f32x4 b0 = *(const f32x4*)(bias + cs + c0), b1 = *(const f32x4*)(bias + cs + c0 + 4);
-          a0 += b0; a1 += b1;
-        }
+        if (bias) { a0 += b0; a1 += b1; }
         if (R) {
-          const f16x8 r = *(const f16x8*)(R + row * ldr + cs + c0);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { a0[e] += (float)r[e]; a1[e] += (float)r[4 + e]; }
         }
@@ -354,6 +391,10 @@ __global__ __launch_bounds__(1024) void gn_reduce_fused_kernel(const float* __re
         *(f16x8*)(c_out + row * ldc + cs + c0) = h;
       } else {
         h = *(const f16x8*)(c_out + row * ldc + cs + c0);
+        if (k == 0) {
+          pga0 = *(const f32x4*)(gamma + cs + c0); pga1 = *(const f32x4*)(gamma + cs + c0 + 4);
+          pbe0 = *(const f32x4*)(beta + cs + c0); pbe1 = *(const f32x4*)(beta + cs + c0 + 4);
+        }
       }
       val[k] = h;
       const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
@@ -395,8 +436,11 @@ __global__ __launch_bounds__(1024) void gn_reduce_fused_kernel(const float* __re
       const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
       const int g1 = g0 + 1 < G ? g0 + 1 : g0;
       const float m0 = st[2 * g0], r0 = st[2 * g0 + 1], m1 = st[2 * g1], r1 = st[2 * g1 + 1];
-      const f32x4 ga0 = *(const f32x4*)(gamma + cs + c0), ga1 = *(const f32x4*)(gamma + cs + c0 + 4);
-      const f32x4 be0 = *(const f32x4*)(beta + cs + c0), be1 = *(const f32x4*)(beta + cs + c0 + 4);
+      f32x4 ga0 = pga0, ga1 = pga1, be0 = pbe0, be1 = pbe1;
+      if (k > 0) {
+        ga0 = *(const f32x4*)(gamma + cs + c0); ga1 = *(const f32x4*)(gamma + cs + c0 + 4);
+        be0 = *(const f32x4*)(beta + cs + c0); be1 = *(const f32x4*)(beta + cs + c0 + 4);
+      }
       f16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
