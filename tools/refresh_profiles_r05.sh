@@ -3,6 +3,15 @@
 # only when their kernel-source hash matches the running build).  Everything lands in gpurun_out/r05_*; copy what should be judged into profiles/.
 export DTP_ROUND=r05
 export DTP_TUNE_CACHE=/tmp/tc.txt
+cp diffusiontexturepainting_amd/tune_seed.txt /tmp/tc.txt   # shapes the shipped table lacks are tuned here and appended: the result is the next shipped table
+python - > gpurun_out/r05_package_probe.log 2>&1 <<'PY'
+import importlib
+for m in ("diffusers", "kornia", "torchvision", "clip", "tornado", "transformers", "onnx", "tensorrt"):
+    try:
+        importlib.import_module(m); print(m, "importable")
+    except Exception as e:
+        print(m, "missing:", type(e).__name__)
+PY
 bash tools/pmc_unet.sh
 cp gpurun_out/r05_pmc_unet_traffic.json profiles/r05_pmc_unet_traffic.json
 bash tools/pmc_unet_mfma.sh > gpurun_out/r05_pmc_unet_mfma.log 2>&1
@@ -26,4 +35,7 @@ cd /tmp && rm -rf /tmp/profm
 timeout 600 rocprofv3 --marker-trace --stats --output-format csv -d /tmp/profm -o r05 -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras > /root/repo/gpurun_out/r05_prof_marker.log 2>&1
 find /tmp/profm -name "*marker*stats*" -exec cp {} /root/repo/gpurun_out/r05_marker_stats.csv \;
 cd /root/repo
+( time timeout 1500 python -m pytest tests -q -m gpu --durations=15 ) > gpurun_out/r05_gpu_suite.log 2>&1
+tail -3 gpurun_out/r05_gpu_suite.log
+cp /tmp/tc.txt gpurun_out/r05_tune_cache.txt
 for f in b1 b8 256; do grep "^{" gpurun_out/r05_$f.log | tail -1 | grep -o "\"ms_per_step\": [0-9.]*"; done
