@@ -2,6 +2,7 @@
 // NHWC fp16 tensors, 16-byte (8 x f16) vector accesses, fp32 statistics, wave64 shuffles.
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -70,7 +71,11 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int ldx, float* __res
   const int c0 = cc * 8;
   const int g0 = c0 / cpg;
   const int split = min(8, (g0 + 1) * cpg - c0);  // elements [0,split) belong to g0, the rest to g0+1 (cpg>=4)
-  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  // a thread owns the same 8 channels for every pixel: sum and sum of squares are kept PER CHANNEL and split between the (at most two)
+  // groups once at the end -- with the split inside the loop every element cost two selects on top of its add and FMA (round 5)
+  float sv[8], qv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sv[e] = qv[e] = 0.f;
   const int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
   const f16* base = x + (size_t)b * HW * ldx + c0;
   int p = p0 + prow;
@@ -83,7 +88,7 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int ldx, float* __res
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float f = (float)v[u][e];
-        if (e < split) { s0 += f; q0 += f * f; } else { s1 += f; q1 += f * f; }
+        sv[e] += f; qv[e] = fmaf(f, f, qv[e]);
       }
   }
   for (; p < p1; p += rows) {
@@ -91,8 +96,13 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int ldx, float* __res
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float f = (float)v[e];
-      if (e < split) { s0 += f; q0 += f * f; } else { s1 += f; q1 += f * f; }
+      sv[e] += f; qv[e] = fmaf(f, f, qv[e]);
     }
+  }
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (e < split) { s0 += sv[e]; q0 += qv[e]; } else { s1 += sv[e]; q1 += qv[e]; }
   }
   part[threadIdx.x * 4 + 0] = s0;
   part[threadIdx.x * 4 + 1] = q0;
@@ -133,7 +143,9 @@ __global__ void gn_stats_reduce_kernel(const float* __restrict__ part, int split
   const int c0 = cbase + cc * 8;
   const int g0 = c0 / cpg;
   const int split = min(8, (g0 + 1) * cpg - c0);
-  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  float sv[8], qv[8];  // per channel, split between the two groups after the loop (see gn_stats_kernel)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sv[e] = qv[e] = 0.f;
   const int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
   f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = {0.f, 0.f, 0.f, 0.f};
   if (bias) { bv0 = *(const f32x4*)(bias + c0); bv1 = *(const f32x4*)(bias + c0 + 4); }
@@ -154,8 +166,13 @@ __global__ void gn_stats_reduce_kernel(const float* __restrict__ part, int split
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float f = (float)h[e];
-      if (e < split) { s0 += f; q0 += f * f; } else { s1 += f; q1 += f * f; }
+      sv[e] += f; qv[e] = fmaf(f, f, qv[e]);
     }
+  }
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (e < split) { s0 += sv[e]; q0 += qv[e]; } else { s1 += sv[e]; q1 += qv[e]; }
   }
   red[threadIdx.x * 4 + 0] = s0;
   red[threadIdx.x * 4 + 1] = q0;
@@ -185,7 +202,7 @@ __global__ void gn_stats_reduce_kernel(const float* __restrict__ part, int split
 __global__ __launch_bounds__(1024) void gn_apply_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ partial, int nchunk, int HW, int C, int cpg,
-                                                        int groups, int silu, float inv_count, float eps) {
+                                                        int groups, int silu, float inv_count, float eps, int hoist) {
   __shared__ float st[64 * 2];
   const int b = blockIdx.y;
   const int nch = C >> 3;
@@ -234,7 +251,58 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const f16* __restrict__ 
     }
   }
   __syncthreads();
-  for (long long i = i_first; i < total; i += (long long)gridDim.x * blockDim.x) {
+  // y = x a + b with a = rstd gamma, b = beta - mean a (per channel of the item's 8, two groups at most)
+  auto affine = [&](int c0, const f32x4& ga, const f32x4& gb, const f32x4& ba, const f32x4& bb, float* a, float* bo) {
+    const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
+    const float m0 = st[g0 * 2], r0 = st[g0 * 2 + 1];
+    const float m1 = st[(g0 + 1 < groups ? g0 + 1 : g0) * 2], r1 = st[(g0 + 1 < groups ? g0 + 1 : g0) * 2 + 1];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gm = e < 4 ? ga[e] : gb[e - 4], bt = e < 4 ? ba[e] : bb[e - 4];
+      const bool first = e < split;
+      a[e] = (first ? r0 : r1) * gm;
+      bo[e] = fmaf(-(first ? m0 : m1), a[e], bt);
+    }
+  };
+  auto emit = [&](auto silu_c, const f16x8& v, const float* a, const float* bo, f16* dst) {  // (SiLU as a compile-time choice: as a flag it was a select per element)
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = fmaf((float)v[e], a[e], bo[e]);
+      if constexpr (decltype(silu_c)::value) f = silu_f(f);
+      o[e] = (f16)f;
+    }
+    *(f16x8*)dst = o;
+  };
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  if (hoist) {
+    // the launcher chose a grid whose stride is a multiple of the chunks per pixel: every item of this thread is the SAME 8 channels,
+    // so the affine pair is formed once (round 5: at batch 8 a thread walks 16 items and the per-item gamma / beta loads, group
+    // selects and products made the pass VALU-bound at half of copy speed)
+    if (i_first < total) {
+      const long long pix0 = i_first / nch;
+      const int c0 = (int)(i_first - pix0 * nch) * 8;
+      float a[8], bo[8];
+      affine(c0, pga, pgb, pba, pbb, a, bo);
+      const long long pstep = stride / nch;
+      auto walk = [&](auto silu_c) {
+        emit(silu_c, pv, a, bo, yb + (size_t)pix0 * ldy + c0);
+        long long pix = pix0 + pstep;
+        for (; pix + pstep < HW; pix += 2 * pstep) {  // two items per trip, loads first
+          const f16x8 v0 = *(const f16x8*)(xb + (size_t)pix * ldx + c0), v1 = *(const f16x8*)(xb + (size_t)(pix + pstep) * ldx + c0);
+          emit(silu_c, v0, a, bo, yb + (size_t)pix * ldy + c0);
+          emit(silu_c, v1, a, bo, yb + (size_t)(pix + pstep) * ldy + c0);
+        }
+        if (pix < HW) {
+          const f16x8 v0 = *(const f16x8*)(xb + (size_t)pix * ldx + c0);
+          emit(silu_c, v0, a, bo, yb + (size_t)pix * ldy + c0);
+        }
+      };
+      if (silu) walk(std::true_type{}); else walk(std::false_type{});
+    }
+    return;
+  }
+  for (long long i = i_first; i < total; i += stride) {
     const long long pix = i / nch;
     const int c0 = (int)(i - pix * nch) * 8;
     f16x8 v = pv;
@@ -244,19 +312,9 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const f16* __restrict__ 
       ga = *(const f32x4*)(gamma + c0); gb = *(const f32x4*)(gamma + c0 + 4);
       ba = *(const f32x4*)(beta + c0); bb = *(const f32x4*)(beta + c0 + 4);
     }
-    const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
-    const float m0 = st[g0 * 2], r0 = st[g0 * 2 + 1];
-    const float m1 = st[(g0 + 1 < groups ? g0 + 1 : g0) * 2], r1 = st[(g0 + 1 < groups ? g0 + 1 : g0) * 2 + 1];
-    f16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float gm = e < 4 ? ga[e] : gb[e - 4], bt = e < 4 ? ba[e] : bb[e - 4];
-      const bool first = e < split;
-      float f = ((float)v[e] - (first ? m0 : m1)) * (first ? r0 : r1) * gm + bt;
-      if (silu) f = silu_f(f);
-      o[e] = (f16)f;
-    }
-    *(f16x8*)(yb + (size_t)pix * ldy + c0) = o;
+    float a[8], bo[8];
+    affine(c0, ga, gb, ba, bb, a, bo);
+    if (silu) emit(std::true_type{}, v, a, bo, yb + (size_t)pix * ldy + c0); else emit(std::false_type{}, v, a, bo, yb + (size_t)pix * ldy + c0);
   }
 }
 
@@ -618,6 +676,18 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* __restrict
 
 }  // namespace
 
+// gn_apply_kernel: round the block count down to a multiple of nch / gcd(nch, 1024) so that the grid stride (blocks x 1024 items) is a
+// multiple of the 8-channel chunks per pixel -- then a thread meets the same channels in every item and hoists the affine pair.
+static int gn_apply_grid(long long* bx, int nch) {
+  int a = nch, b = 1024;
+  while (b) { const int t = a % b; a = b; b = t; }
+  const int q = nch / a;
+  if (*bx < q) return 0;
+  *bx -= *bx % q;
+  return 1;
+}
+
+
 // statistics-with-reduce pass: pixel chunks and the channel slab of a block (see gn_stats_reduce_kernel)
 static int gn_chunks_reduce(int HW) { return HW >= 1024 ? (HW / 64 > 128 ? 128 : HW / 64) : (HW >= 32 ? HW / 32 : 1); }
 static int gn_slab_channels(int HW, int C, int cpg) {
@@ -695,8 +765,9 @@ static int groupnorm_two_pass(const f16* x, int ldx, f16* y, int ldy, const floa
   long long bx = (per_batch + at - 1) / at;
   const long long cap = std::max<long long>(1, 256 / B);
   if (bx > cap) bx = cap;
+  const int hoist = gn_apply_grid(&bx, C / 8);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((int)bx, B), dim3(at), 0, s, x, ldx, y, ldy, gamma, beta, ws, nchunk, HW, C, cpg,
-                     groups, silu, 1.0f / ((float)HW * cpg), eps);
+                     groups, silu, 1.0f / ((float)HW * cpg), eps, hoist);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
@@ -710,8 +781,9 @@ int dtp_launch_groupnorm_apply(const f16* x, int ldx, f16* y, int ldy, const flo
   long long bx = (per_batch + 1023) / 1024;
   const long long cap = std::max<long long>(1, 256 / B);
   if (bx > cap) bx = cap;
+  const int hoist = gn_apply_grid(&bx, C / 8);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((int)bx, B), dim3(1024), 0, s, x, ldx, y, ldy, gamma, beta, partial, nchunk, HW, C, C / groups, groups, silu,
-                     1.0f / ((float)HW * (C / groups)), eps);
+                     1.0f / ((float)HW * (C / groups)), eps, hoist);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 

@@ -1,0 +1,8 @@
+#!/bin/bash
+# GroupNorm apply with the affine pair hoisted out of the item loop: parity tests, then A/B against the HEAD build (same tune table file)
+mkdir -p gpurun_out
+cp diffusiontexturepainting_amd/tune_seed.txt /tmp/ab_tc.txt
+export DTP_TUNE_CACHE=/tmp/ab_tc.txt
+timeout 900 python -m pytest tests/test_gpu_ops.py -q -x -k "norm or gn or conv" > gpurun_out/r05_gnh_ops.log 2>&1; tail -3 gpurun_out/r05_gnh_ops.log
+timeout 900 python -m pytest tests/test_gpu_engine.py tests/test_gpu_round2.py -q -x > gpurun_out/r05_gnh_engine.log 2>&1; tail -3 gpurun_out/r05_gnh_engine.log
+bash tools/ab.sh tools/ab/libdtp_head.so all 3
