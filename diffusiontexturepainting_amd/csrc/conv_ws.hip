@@ -121,21 +121,35 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
   // whole weight set fits any L2) the units of one pixel group sit on one XCD and share its patches.
   // H x W: the map the 3x3 window slides over = the output map (stride 1); with GF_UPS2 it is the nearest-2x upsample of the stored
   // Hi x Wi input, which only the patch DMA's source addresses know about
+  // (round 5: this decode was nine integer divisions, two of them 64-bit -- ~500 instructions in front of the first memory request of
+  // a 20-50 us launch.  Map sizes and tile counts are powers of two everywhere in this model: shifts on that path, one division pair
+  // for the block index, none for the K-slices of an unsplit launch; the general forms stay as the fallback.)
   const int H = p.Ho, W = p.Wo;
-  const int tiles_x = W / TW, tiles_y = H / TH;
-  const int npg = (p.M / (H * W) / NI) * tiles_y * tiles_x;
+  const int tiles_x = W / TW, tiles_y = H / TH;  // (TW, TH: compile-time powers of two)
+  const int hw = H * W;
+  const bool pow2 = ((hw & (hw - 1)) | (tiles_x & (tiles_x - 1)) | (tiles_y & (tiles_y - 1))) == 0;
+  const int images = pow2 ? (p.M >> __builtin_ctz(hw)) : p.M / hw;
+  const int npg = (images / NI) * tiles_y * tiles_x;
   const int nts = (p.N + 31) >> 5, nrs = (nts + NT - 1) / NT, S = p.splits;
   const int units = nrs * S;
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   int pg, u;
-  if ((units & 7) == 0) { pg = idx % npg; u = (idx / npg) * 8 + xcd; }
-  else { const int pgq = (npg + 7) >> 3; pg = (idx % pgq) * 8 + xcd; u = idx / pgq; }
+  if ((units & 7) == 0) { const int q = idx / npg; pg = idx - q * npg; u = q * 8 + xcd; }
+  else { const int pgq = (npg + 7) >> 3; const int q = idx / pgq; pg = (idx - q * pgq) * 8 + xcd; u = q; }
   if (u >= units || pg >= npg) return;
-  const int z = u % S, nr = u / S;
   const int ncb = p.Cin >> 6;
-  const int mb0 = (int)((long long)z * ncb / S), mb1 = (int)((long long)(z + 1) * ncb / S);  // channel blocks [mb0, mb1)
-  const int tx = pg % tiles_x, ty = (pg / tiles_x) % tiles_y;
-  const int img0 = (pg / (tiles_x * tiles_y)) * NI;
+  int z = 0, nr = u, mb0 = 0, mb1 = ncb;  // channel blocks [mb0, mb1)
+  if (S > 1) {
+    nr = u / S; z = u - nr * S;
+    mb0 = z * ncb / S; mb1 = (z + 1) * ncb / S;  // (S <= Cin / 64 <= 40: 32-bit)
+  }
+  int tx, ty, img0;
+  if (pow2) {
+    const int sx = __builtin_ctz(tiles_x), sy = __builtin_ctz(tiles_y);
+    tx = pg & (tiles_x - 1); ty = (pg >> sx) & (tiles_y - 1); img0 = (pg >> (sx + sy)) * NI;
+  } else {
+    tx = pg % tiles_x; ty = (pg / tiles_x) % tiles_y; img0 = (pg / (tiles_x * tiles_y)) * NI;
+  }
   const int y0 = ty * TH, x0 = tx * TW;
 
   // ---- weight ring first: fragment (n-tile, cb, tap) of this wave's channel quarter; the loads of the first channel block are in

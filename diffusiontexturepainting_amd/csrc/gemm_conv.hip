@@ -137,12 +137,17 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
   };
   f16x8 r0 = {0, 0, 0, 0, 0, 0, 0, 0}, r1 = r0, r2 = r0;
   constexpr bool HOIST = BM * BN <= 64 * 128;
-  if constexpr (HOIST) {
-    if (p.splits == 1 && !(fl & GF_GEGLU) && tid < NT) {
-      load_cols();
-      if (pre_r) { r0 = load_r(0); r1 = load_r(1); r2 = load_r(2); }
+  // (round 5: requested right BEHIND the first k-block's DMA pieces instead of in front of them -- the hoist is ~150 instructions, and
+  // the first DMA of a 10 us launch waited for all of them.  Older than every later stage, so a counted vmcnt that leaves only whole
+  // younger stages outstanding still covers them.)
+  auto hoist_epilogue_operands = [&]() {
+    if constexpr (HOIST) {
+      if (p.splits == 1 && !(fl & GF_GEGLU) && tid < NT) {
+        load_cols();
+        if (pre_r) { r0 = load_r(0); r1 = load_r(1); r2 = load_r(2); }
+      }
     }
-  }
+  };
 
 
   // ---- DMA source state.  Row r = i*RPR + wave*8 + (lane>>3); LDS slot = lane&7 holds source
@@ -290,9 +295,12 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
       }
       return;
     }
+    hoist_epilogue_operands();  // consumer waves: their own vmcnt
   } else {
+    if (0 < nk) issue(0, kb0);
+    hoist_epilogue_operands();
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
+    for (int s = 1; s < NS - 1; ++s)
       if (s < nk) issue(s, kb0 + s);
   }
   // ---- fused LayerNorm (GF_LNFOLD): while the first DMA stages are in flight, compute mean / rstd of this tile's
