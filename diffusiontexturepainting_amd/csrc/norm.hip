@@ -270,6 +270,10 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const f16* __restrict__ 
     for (int e = 0; e < 8; ++e) {
       float f = fmaf((float)v[e], a[e], bo[e]);
       if constexpr (decltype(silu_c)::value) f = silu_f(f);
+      // keep f a 32-bit value up to the conversion: left alone, hipcc fuses the last multiply (or the FMA) with the f16 conversion on SOME
+      // elements of SOME inlined copies of this lambda (v_fma_mixlo / mixhi_f16: one rounding instead of two), so which copy handled an
+      // item -- i.e. the grid, i.e. the batch size -- decided its last bit, and the de-duplicated UNet prefix stopped being bit-identical
+      asm volatile("" : "+v"(f));
       o[e] = (f16)f;
     }
     *(f16x8*)dst = o;
