@@ -7,6 +7,10 @@ multi-head attention is an independent code path), the GroupNorm / LayerNorm eps
 (norm -> SiLU -> conv, time embedding added between the convolutions, 1x1 shortcut when the widths differ), GEGLU's chunk order
 against an explicit split, the strict key scheme (load_state_dict(strict=True) of the oracle's key slice must succeed: no missing
 and no unexpected parameter in any block type).
+Round 5, second half: the WHOLE graphs as well -- UNet2DConditionModel and AutoencoderKL assembled module-style in the diffusers layout
+(down / mid / up blocks with their samplers, the time-embedding MLP, the VAE's asymmetric pad), load_state_dict(strict=True) of the complete
+state dicts (686 / 248 tensors), forward at a small map against unet_forward / vae_encode / vae_decode: pins skip order, sampler placement
+and the time-embedding path.
 What it does NOT pin: that diffusers 0.12 itself computes this -- the package is importable nowhere here (DESIGN.md section 5);
 tests/test_oracle_thirdparty.py keeps the fixture / live comparisons that will, the day the packages are.
 """
@@ -234,3 +238,223 @@ def test_every_unet_and_vae_parameter_belongs_to_a_block_the_oracle_evaluates(un
     vae_blocks = {".".join(k.split(".")[:k.split(".").index("resnets") + 2]) for k in vae_sd if ".resnets." in k}
     for b in sorted(vae_blocks):
         _load(ResnetBlock2D(vae_sd[b + ".norm1.weight"].shape[0], vae_sd[b + ".conv1.weight"].shape[0], 0, 1e-6), vae_sd, b)
+
+
+# ----------------------------------------------------------------------------- whole graphs
+# The block tests above pin every block's arithmetic; the assemblies below pin the WIRING of oracle/nets.py's unet_forward / vae_encode /
+# vae_decode -- skip order, where the samplers sit, what the time embedding feeds, the VAE's asymmetric down-sampling pad -- against a
+# second, module-style assembly in the diffusers layout (CrossAttnDownBlock2D / DownBlock2D / UNetMidBlock2DCrossAttn / CrossAttnUpBlock2D /
+# UpBlock2D; Encoder / Decoder with DownEncoderBlock2D / UpDecoderBlock2D) that must swallow the WHOLE state dict with strict=True.
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, c, padding):
+        super().__init__()
+        self.pad = padding
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=padding)
+
+    def forward(self, x):
+        if self.pad == 0:  # the VAE encoder: F.pad(x, (0, 1, 0, 1)) in front of an unpadded stride-2 conv
+            x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0.0)
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cin, cout, temb, attn, sampler, eps=1e-5, pad=1):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if j == 0 else cout, cout, temb, eps) for j in range(2)])
+        if attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, 8) for _ in range(2)])
+        if sampler:
+            self.downsamplers = nn.ModuleList([Downsample2D(cout, pad)])
+
+    def forward(self, x, temb, ctx):
+        outs = []
+        for j, r in enumerate(self.resnets):
+            x = r(x, temb)
+            if hasattr(self, "attentions"):
+                x = self.attentions[j](x, ctx)
+            outs.append(x)
+        if hasattr(self, "downsamplers"):
+            x = self.downsamplers[0](x)
+            outs.append(x)
+        return x, outs
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cprev, cskips, cout, temb, attn, sampler):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D((cprev if j == 0 else cout) + cskips[j], cout, temb, 1e-5) for j in range(3)])
+        if attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, 8) for _ in range(3)])
+        if sampler:
+            self.upsamplers = nn.ModuleList([Upsample2D(cout)])
+
+    def forward(self, x, skips, temb, ctx):
+        for j, r in enumerate(self.resnets):
+            x = r(torch.cat([x, skips.pop()], dim=1), temb)
+            if hasattr(self, "attentions"):
+                x = self.attentions[j](x, ctx)
+        if hasattr(self, "upsamplers"):
+            x = self.upsamplers[0](x)
+        return x
+
+
+class MidBlock(nn.Module):
+    def __init__(self, c, temb):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb, 1e-5) for _ in range(2)])
+        self.attentions = nn.ModuleList([Transformer2DModel(c, 8)])
+
+    def forward(self, x, temb, ctx):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x, temb), ctx), temb)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, cin, c):
+        super().__init__()
+        self.linear_1, self.linear_2 = nn.Linear(cin, c), nn.Linear(c, c)
+
+    def forward(self, t):
+        return self.linear_2(F.silu(self.linear_1(t)))
+
+
+class UNet2DConditionModel(nn.Module):
+    """SD-1.5 inpainting UNet (9 input channels, block_out_channels 320/640/1280/1280, 2 layers per block, 8 heads, cross-attention dim 768)."""
+
+    def __init__(self):
+        super().__init__()
+        ch = (320, 640, 1280, 1280)
+        self.conv_in = nn.Conv2d(9, 320, 3, padding=1)
+        self.time_embedding = TimestepEmbedding(320, 1280)
+        self.down_blocks = nn.ModuleList([DownBlock(ch[max(i - 1, 0)], ch[i], 1280, attn=i < 3, sampler=i < 3) for i in range(4)])
+        self.mid_block = MidBlock(1280, 1280)
+        rev = ch[::-1]
+        ups = []
+        for i in range(4):  # skip widths, in the order they are popped: the block's own level twice, then the level above (or conv_in)
+            own, above = rev[i], rev[min(i + 1, 3)]
+            ups.append(UpBlock(rev[max(i - 1, 0)], (own, own, above), own, 1280, attn=i > 0, sampler=i < 3))
+        self.up_blocks = nn.ModuleList(ups)
+        self.conv_norm_out = nn.GroupNorm(32, 320, eps=1e-5)
+        self.conv_out = nn.Conv2d(320, 4, 3, padding=1)
+
+    def forward(self, sample, t, ctx):
+        half = 160  # Timesteps(320, flip_sin_to_cos=True, downscale_freq_shift=0), written with numpy-style powers instead of exp(log)
+        freqs = torch.tensor([10000.0 ** (-k / half) for k in range(half)], dtype=torch.float64)
+        arg = float(t) * freqs
+        temb = self.time_embedding(torch.cat([torch.cos(arg), torch.sin(arg)]).float()[None].expand(sample.shape[0], -1))
+        x = self.conv_in(sample)
+        skips = [x]
+        for blk in self.down_blocks:
+            x, outs = blk(x, temb, ctx)
+            skips += outs
+        x = self.mid_block(x, temb, ctx)
+        for blk in self.up_blocks:
+            x = blk(x, skips, temb, ctx)
+        assert not skips
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
+class VaeMid(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, 0, 1e-6) for _ in range(2)])
+        self.attentions = nn.ModuleList([AttentionBlock(c)])
+
+    def forward(self, x):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x)))
+
+
+class VaeEncoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        ch = (128, 256, 512, 512)
+        self.conv_in = nn.Conv2d(3, 128, 3, padding=1)
+        self.down_blocks = nn.ModuleList([DownBlock(ch[max(i - 1, 0)], ch[i], 0, attn=False, sampler=i < 3, eps=1e-6, pad=0) for i in range(4)])
+        self.mid_block = VaeMid(512)
+        self.conv_norm_out = nn.GroupNorm(32, 512, eps=1e-6)
+        self.conv_out = nn.Conv2d(512, 8, 3, padding=1)
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for blk in self.down_blocks:
+            x, _ = blk(x, None, None)
+        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+
+
+class VaeUpBlock(nn.Module):
+    def __init__(self, cin, cout, sampler):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if j == 0 else cout, cout, 0, 1e-6) for j in range(3)])
+        if sampler:
+            self.upsamplers = nn.ModuleList([Upsample2D(cout)])
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        return self.upsamplers[0](x) if hasattr(self, "upsamplers") else x
+
+
+class VaeDecoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        ch = (512, 512, 256, 128)
+        self.conv_in = nn.Conv2d(4, 512, 3, padding=1)
+        self.mid_block = VaeMid(512)
+        self.up_blocks = nn.ModuleList([VaeUpBlock(ch[max(i - 1, 0)], ch[i], sampler=i < 3) for i in range(4)])
+        self.conv_norm_out = nn.GroupNorm(32, 128, eps=1e-6)
+        self.conv_out = nn.Conv2d(128, 3, 3, padding=1)
+
+    def forward(self, z):
+        x = self.mid_block(self.conv_in(z))
+        for blk in self.up_blocks:
+            x = blk(x)
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
+class AutoencoderKL(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.encoder, self.decoder = VaeEncoder(), VaeDecoder()
+        self.quant_conv, self.post_quant_conv = nn.Conv2d(8, 8, 1), nn.Conv2d(4, 4, 1)
+
+
+def test_whole_unet_graph_against_a_module_style_assembly(unet_sd):
+    net = UNet2DConditionModel()
+    net.load_state_dict(unet_sd, strict=True)  # every one of the 686 tensors has a home, none is missing
+    net.eval()
+    g = torch.Generator().manual_seed(SEED + 5)
+    sample = torch.randn(2, 9, 16, 16, generator=g)  # a 128^2 stamp's latent: three down-samplings leave 2 x 2
+    ctx = torch.randn(2, 14, 768, generator=g)
+    for t in (981.0, 401.0, 1.0):
+        with torch.no_grad():
+            ref = nets.unet_forward(unet_sd, sample, t, ctx)
+            got = net(sample, t, ctx)
+        _close(got, ref, tol=1e-4)
+
+
+def test_whole_vae_graphs_against_a_module_style_assembly(vae_sd):
+    vae = AutoencoderKL()
+    vae.load_state_dict(vae_sd, strict=True)
+    vae.eval()
+    g = torch.Generator().manual_seed(SEED + 6)
+    img = torch.rand(1, 3, 64, 64, generator=g) * 2 - 1
+    eps = torch.randn(1, 4, 8, 8, generator=g)
+    with torch.no_grad():
+        mom = vae.quant_conv(vae.encoder(img))
+        mean, logvar = mom[:, :4], mom[:, 4:].clamp(-30.0, 20.0)
+        rm, rl = nets.vae_encode_moments(vae_sd, img)
+        _close(mean, rm, tol=1e-4)
+        _close(logvar, rl, tol=1e-4)
+        _close(mean + torch.exp(0.5 * logvar) * eps, nets.vae_encode(vae_sd, img, eps), tol=1e-4)
+        z = torch.randn(1, 4, 8, 8, generator=g)
+        _close(vae.decoder(vae.post_quant_conv(z)), nets.vae_decode(vae_sd, z), tol=1e-4)
