@@ -97,6 +97,26 @@ def test_config2_batch8_consistent_with_single_stamps(model512):
         assert err <= 1e-2
 
 
+def test_batch16_sub_batched_vae_consistent_with_single_stamps(weights):
+    """The reference engines' max_batch (trt_model.py:44).  At 512^2 a batch of 16 makes the VAE encoder's 32 images x 128 channels (and
+    the decoder's 16 x 256) reach the 2 GiB range of a buffer descriptor: the VAE programs run the batch as sub-batches (vae.hip,
+    round 5).  Stamps 0, 9 and 15 -- first sub-batch, second sub-batch, last image -- must match the same stamps run alone."""
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    m = MI355ConditionalInpainter(512, device=0, weights=weights[0], max_batch=16)
+    canvas, brush, cond, uncond, lat, eps = _inputs(16, 512, 900)
+    st = dict(steps=4, context_pad=150, tg_steps=4, cfg_weight=2.0, tg_weight=1.0)
+    m.set_conditioning(cond, uncond, brush)
+    batch = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
+    torch.cuda.synchronize()
+    assert batch.shape == (16, 3, 512, 512) and torch.isfinite(batch).all() and batch.std() > 1e-3
+    for i in (0, 9, 15):
+        single = m.generate_raw(canvas[i:i + 1], latents=lat[i:i + 1], vae_eps=eps[:, i:i + 1], **st)
+        err = (single - batch[i:i + 1]).abs().max().item()
+        print("batch-16 vs single stamp", i, err)
+        assert err <= 1e-2
+    del m
+
+
 def test_256_10steps_matches_cpu_oracle(weights):
     """The reference server's own resolution (run.py:30: 256): 9 UNet evaluations of accumulated fp16 error against the fp32 oracle,
     texture guidance cut off mid-loop so both launch programs run (the 19-evaluation case is the 512^2 test below; this one was 20
