@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+CONTRACTION_KERNELS = ("gemm_kernel", "conv_halo_kernel", "gemm_wide_kernel", "xattn_kernel", "lnlin_kernel", "convws_kernel")
 PMC_TRAFFIC_FILE = "r05_pmc_unet_traffic.json"  # tools/pmc_unet.sh, committed with the sha1 of the kernel sources it was collected on
 
 
@@ -116,9 +117,7 @@ def pmc_mfma():
     if t.get("kernel_source_hash") != kernel_source_hash():
         return {"mfma_busy": None, "mfma_busy_note": f"profiles/{PMC_MFMA_FILE} was collected on build {t.get('kernel_source_hash')}, "
                                                      f"this build is {kernel_source_hash()}: not reported"}
-    return {"mfma_busy": t["class_mfma_busy"], "mfma_busy_unit": "fraction of SIMD cycles with the matrix pipe busy (SQ_VALU_MFMA_BUSY_CYCLES / "
-                                                                 "(1024 SIMDs x GRBM_GUI_ACTIVE / 8)), contraction class, eager launches",
-            "mfma_busy_per_kernel": t["per_kernel"], "mfma_busy_source": f"profiles/{PMC_MFMA_FILE}"}
+    return {"mfma_busy": t["class_mfma_busy"], "mfma_busy_source": f"profiles/{PMC_MFMA_FILE}"}
 
 
 def measured_peaks():
@@ -170,12 +169,10 @@ def extra_measurements(model512, sd):
     # round 5: the fp8 variant of configs[4] is no longer timed here.  It is a PARITY-ONLY option (fp8_attention / fp8_linear: inside the
     # 1e-2 pixel gate on both weight sets, tests/test_gpu_fullsize.py) that three rounds of measurements never made faster than fp16 on
     # this chip (23.5 vs 23.2 ms at 256^2 / 8 steps in round 4's driver run): the fp16 line above IS configs[4]'s workload.
-    out["configs[4]_fp8"] = {"status": "parity-only option, not a performance path: never faster than fp16 here (DESIGN.md 4)",
-                             "how_to_time_it": "DTP_FP8=1 python bench.py --res 256 --ddim-steps 8 --no-extras"}
+    out["configs[4]_fp8"] = "parity-only option (DESIGN.md 4); DTP_FP8=1 python bench.py --res 256 --ddim-steps 8 --no-extras"
     if model512.max_batch >= 16:
         ms16 = time_stamps(model512, 16, 512, 20, n=2, warm=1, seed=2400)
-        out["batch16_512px_20steps"] = {"stamps_per_s": 16e3 / ms16, "ms_per_batch": ms16, "timed_batches": 2, "dtype": "f16",
-                                        "note": "the reference engines' max_batch (trt_model.py:44)"}
+        out["batch16_512px_20steps"] = {"stamps_per_s": 16e3 / ms16, "ms_per_batch": ms16, "timed_batches": 2, "dtype": "f16"}  # trt_model.py:44 max_batch
     m64 = MI355ConditionalInpainter(64, device=model512._index, weights=sd, max_batch=2)
     canvas, brush, lat, eps = synthetic.make_stamp_batch(2, 64, seed=2300)
     cond, uncond = synthetic.make_conditioning(8)
@@ -183,9 +180,127 @@ def extra_measurements(model512, sd):
     st = dict(steps=4, context_pad=9, tg_steps=4, cfg_weight=2.0, tg_weight=1.0)
     got = m64.generate_raw(canvas, latents=lat, vae_eps=eps, **st).cpu()
     ref = pipeline.generate_raw(dict(unet=nets.merge_lora(sd["unet"], sd["lora"]), vae=sd["vae"]), brush, cond, uncond, canvas, lat, eps, **st)
-    out["pixel_max_abs_err_vs_cpu_oracle"] = {"value": (got - ref).abs().max().item(), "gate": 1e-2,
-                                              "case": "2 x 64x64 stamps, 4 DDIM steps, same weights / noise on both sides"}
+    out["pixel_max_abs_err_vs_cpu_oracle"] = {"value": (got - ref).abs().max().item(), "gate": 1e-2, "case": "2 x 64x64 stamps, 4 DDIM steps"}
     return out
+
+
+LINE_LIMIT = 6000  # bytes: the driver keeps an 8 KB tail of stdout and parses the last line of it (round 5's 27 KB line was lost)
+
+
+def roofline_record(rows, classes, batch, res, ddim_steps, step_s, peak_tf, peak_gbs):
+    """(`roofline` object of the JSON line -- scalars only --, detail tables for the side file) from the per-kernel rows of one profiled
+    stamp (HIP events around every launch on its stream, dtp_profile_rows) and the per-label classes of the same pass."""
+    tot_ms = sum(r["ms"] for r in rows)
+    gem = [r for r in rows if r["kernel"].startswith(CONTRACTION_KERNELS)]
+    # dominant kernel = the implicit-GEMM kernel class; its most time-consuming instantiation is the headline row
+    dom = max(gem, key=lambda r: r["ms"])
+    g_ms, g_fl, g_n = sum(r["ms"] for r in gem), sum(r["flops"] for r in gem), sum(r["launches"] for r in gem)
+    ach = g_fl / (g_ms * 1e-3) / 1e12
+    gn = [r for r in rows if r["kernel"].startswith("gn_")]
+    roof = {
+        "bound": "mfma", "kernel": "implicit-GEMM conv / linear / fused-attention-linear class (" + " + ".join(k for k in CONTRACTION_KERNELS) + ")",
+        "achieved": ach, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16_TFLOPS,
+        "peak_measured": peak_tf, "frac_of_measured": ach / peak_tf if peak_tf else None,
+        "hbm_peak": PEAK_HBM_GBS, "hbm_peak_measured": peak_gbs,
+        "launches": g_n, "avg_launch_us": g_ms * 1e3 / g_n, "class_ms_per_step": g_ms, "share_of_gpu_time": g_ms / tot_ms,
+        "algorithmic_tflop_per_step": g_fl / 1e12, "algorithmic_bytes_per_launch": sum(r["bytes"] for r in gem) / g_n,
+        **pmc_traffic(batch), **pmc_mfma(),
+        "groupnorm_ms_per_step": sum(r["ms"] for r in gn), "groupnorm_launches": sum(r["launches"] for r in gn),
+        "standalone_splitk_reduce_launches": classes["standalone_splitk_reduce_launches"],
+        "kernel_launches_per_step": sum(r["launches"] for r in rows), "kernel_ms_per_step": tot_ms,
+        "dominant_instantiation": {"kernel": dom["kernel"], "launches": dom["launches"], "avg_launch_us": dom["ms"] * 1e3 / dom["launches"],
+                                   "achieved": dom["flops"] / (dom["ms"] * 1e-3) / 1e12,
+                                   "frac": dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS},
+    }
+    if (res, ddim_steps) == (512, 20):  # the whole stamp against the same peak: SURVEY 8d's 50.49 TFLOP per stamp in the reference's formulation
+        ws = 50.49 * batch / step_s
+        roof["whole_stamp"] = {"tflop": 50.49 * batch, "achieved": ws, "frac": ws / PEAK_MFMA_F16_TFLOPS}
+    detail = {
+        "peak_measured_note": "v_mfma_f32_32x32x16_f16 issue rate, one wave per SIMD on every CU, random operands, measured on this box before "
+                              "the timed region (csrc/peaks.hip); hbm_peak_measured = float4 copy, read + write bytes",
+        "kernel_source_hash": kernel_source_hash(), **classes,
+        "kernels": [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["ms"], 3), "avg_us": round(r["ms"] * 1e3 / r["launches"], 2),
+                     "share": round(r["ms"] / tot_ms, 4), "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1),
+                     "algo_GBps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1),
+                     # HBM-bound classes (GroupNorm, LayerNorm, elementwise): algorithmic bytes per second against the measured copy rate
+                     **({"hbm_frac_of_measured": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9 / peak_gbs, 4)} if r["flops"] == 0 and r["bytes"] > 0 and peak_gbs else {})}
+                    for r in rows],
+    }
+    return roof, detail
+
+
+def compose_line(*, batch, res, ddim_steps, world, steps, warmup, elapsed, lat_ms, stage, info, roof, cpu, extras, backend="nccl",
+                 distributed=False, fp8_attention=False, fp8_linear=False, launched_by_bench=False):
+    """The ONE JSON line of the bench contract, from measured scalars (no GPU needed to call this: tests/test_bench_contract.py builds a
+    line from a stubbed measurement and checks the contract fields and the size bound)."""
+    n_total = batch * world
+    lat_sorted = sorted(lat_ms)
+    cfg_idx = {(1, 512, 20): 1, (8, 512, 20): 2, (1, 256, 8): 4}.get((batch, res, ddim_steps))
+    if (batch, res, ddim_steps, world) == (8, 512, 20, 8):
+        cfg_idx = 3  # batch 64 = 8 stamps on each of 8 GPUs, one gather of the decoded patches to rank 0
+    cfg_name = f"BASELINE.json configs[{cfg_idx}]" if cfg_idx is not None else "not a BASELINE.json configuration"
+    if world > 1 and cfg_idx in (1, 2):
+        cfg_name += f" per GPU x {world} GPUs (weak scaling)"
+    if cfg_idx == 4:
+        cfg_name += " workload in fp16 (the fp8 variant is selected with DTP_FP8=1)"
+    return {
+        "metric": "512x512 inpaint stamps/sec @20 DDIM steps" if (res, ddim_steps) == (512, 20) else
+                  f"{res}x{res} inpaint stamps/sec @{ddim_steps} DDIM steps",
+        "value": n_total * steps / elapsed, "unit": "stamps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": ("f8e4m3 attention" + (" + linear" if fp8_linear else "") + " + f16") if fp8_attention else "f16", "data": "synthetic",
+        "config": {"workload": f"{cfg_name}: {batch} x {res}x{res} RGBA stamp(s) per GPU, {ddim_steps} DDIM steps = {ddim_steps - 1} UNet evals "
+                               "(reference quirk), 3 guidance branches, cfg 2.0 / tg 1.0 / tg_steps = steps / context_pad 150, SD-1.5-inpaint "
+                               "UNet + LoRA merged + AutoencoderKL, seeded synthetic weights, conditioning cached",
+                   "stamps_per_gpu_per_step": batch, "resolution": res, "ddim_steps": ddim_steps,
+                   "unet_evals": info["unet_evals"], "graph_nodes": info["graph_nodes"],
+                   "gather": f"{'rccl' if backend == 'nccl' else backend} gather of u8 patches to rank 0, timed" if distributed else "none (1 GPU)",
+                   "ranks_launched_by": "bench.py" if launched_by_bench else ("torch.distributed.run" if distributed else "single process")},
+        "p50_stamp_latency_ms": lat_sorted[len(lat_sorted) // 2], "p95_stamp_latency_ms": lat_sorted[int(len(lat_sorted) * 0.95)],
+        "stage_ms": {"pre+vae_encode_x2": stage[0], "denoise_loop": stage[1], "vae_decode+post": stage[2]},
+        "roofline": roof, "cpu_baseline": cpu, "extra_configs": extras,
+    }
+
+
+def _round_floats(o, nd=5):
+    """Floats to `nd` significant digits (json prints 17): a third of the line's bytes were digits nobody reads."""
+    if isinstance(o, float):
+        return float(f"{o:.{nd}g}") if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {k: _round_floats(v, nd) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_round_floats(v, nd) for v in o]
+    return o
+
+
+def emit(line):
+    """Serialise the line (no NaN / Infinity literals, 6 significant digits) and REFUSE to print one the driver could not parse."""
+    text = json.dumps(_round_floats(line, 6), allow_nan=False, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:
+        # never lose the headline again: drop the optional objects, largest first, and say so
+        slim = dict(line)
+        for key in ("extra_configs", "stage_ms"):
+            slim[key] = None
+            slim["dropped_for_size"] = slim.get("dropped_for_size", []) + [key]
+            text = json.dumps(_round_floats(slim, 6), allow_nan=False, separators=(",", ":"))
+            if len(text) <= LINE_LIMIT:
+                break
+    assert len(text) <= LINE_LIMIT and "\n" not in text, len(text)
+    json.loads(text)
+    return text
+
+
+def write_detail(path, detail):
+    """Per-kernel / per-class tables of the profiled pass go to a side file (default gpurun_out/bench_detail.json: it travels back from the
+    GPU box), never into the line."""
+    path = path or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(_round_floats(detail, 6), f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError as e:
+        return f"not written: {e}"
 
 
 # ---------------------------------------------------------------------------------------------------- multi-rank launch
@@ -329,6 +444,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra configurations (batch 8, 256 px, oracle pixel error)")
     ap.add_argument("--dump-launches", default="", help="CSV with one line per profiled kernel launch")
+    ap.add_argument("--detail", default="", help="side file for the per-kernel tables (default gpurun_out/bench_detail.json)")
     a = ap.parse_args()
     if a.cpu_config0:
         print(json.dumps(cpu_config0()))
@@ -402,7 +518,7 @@ def main():
     stage = model.stage_times_ms()
     info = model.stamp_info()
 
-    roof = None
+    roof = detail = None
     if not a.no_profile and rank == 0:
         # one more pass of the same stamp with every launch bracketed by HIP events on its stream
         model.profile(True)
@@ -414,41 +530,7 @@ def main():
         if not a.dump_launches:
             os.unlink(dump_path)
         model.profile(False)
-        tot_ms = sum(r["ms"] for r in rows)
-        gem = [r for r in rows if r["kernel"].startswith(("gemm_kernel", "conv_halo_kernel", "gemm_wide_kernel", "xattn_kernel", "lnlin_kernel", "convws_kernel"))]
-        # dominant kernel = the implicit-GEMM kernel; its most time-consuming instantiation is the headline row
-        dom = max(gem, key=lambda r: r["ms"])
-        g_ms, g_fl, g_n = sum(r["ms"] for r in gem), sum(r["flops"] for r in gem), sum(r["launches"] for r in gem)
-        roof = {
-            "bound": "mfma", "kernel": "gemm_kernel<BM,BN,NS,KH,LW> + gemm_wide_kernel<BM,BN> + conv_halo_kernel<TH,TW,BN,GN,NI> + convws_kernel<TH,TW,NI> + lnlin_kernel<KU,GEGLU> + xattn_kernel (implicit-GEMM conv/linear, all instantiations)",
-            "achieved": g_fl / (g_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-            "frac": g_fl / (g_ms * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS,
-            "peak_measured": peak_tf, "frac_of_measured": g_fl / (g_ms * 1e-3) / 1e12 / peak_tf,
-            "peak_measured_note": "v_mfma_f32_32x32x16_f16 issue rate, one wave per SIMD on every CU, random operands, measured on this box "
-                                  "before the timed region (csrc/peaks.hip); hbm_peak_measured = float4 copy, read + write bytes",
-            "hbm_peak": PEAK_HBM_GBS, "hbm_peak_measured": peak_gbs,
-            "launches": g_n, "avg_launch_us": g_ms * 1e3 / g_n, "share_of_gpu_time": g_ms / tot_ms,
-            "algorithmic_tflop_per_step": g_fl / 1e12,
-            "algorithmic_bytes_per_launch": sum(r["bytes"] for r in gem) / g_n,
-            **classes,
-            **pmc_traffic(a.batch),
-            **pmc_mfma(),
-            # the whole stamp against the same peak: SURVEY 8d's 50.49 TFLOP per 512^2 / 20-step stamp in the reference's formulation
-            **({"whole_stamp": {"tflop_reference_formulation": 50.49 * a.batch, "achieved": 50.49 * a.batch / (elapsed / a.steps),
-                                "frac": 50.49 * a.batch / (elapsed / a.steps) / PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s"}}
-               if (a.res, a.ddim_steps) == (512, 20) else {}),
-            "dominant_instantiation": {"kernel": dom["kernel"], "launches": dom["launches"],
-                                       "avg_launch_us": dom["ms"] * 1e3 / dom["launches"],
-                                       "achieved": dom["flops"] / (dom["ms"] * 1e-3) / 1e12,
-                                       "frac": dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS},
-            "kernels": [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["ms"], 3),
-                         "avg_us": round(r["ms"] * 1e3 / r["launches"], 2), "share": round(r["ms"] / tot_ms, 4),
-                         "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1),
-                         "algo_GBps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1),
-                         # HBM-bound classes (GroupNorm, LayerNorm, elementwise): algorithmic bytes per second against the measured copy rate
-                         **({"hbm_frac_of_measured": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9 / peak_gbs, 4)} if r["flops"] == 0 and r["bytes"] > 0 else {})}
-                        for r in rows],
-        }
+        roof, detail = roofline_record(rows, classes, a.batch, a.res, a.ddim_steps, elapsed / a.steps, peak_tf, peak_gbs)
     cpu = None
     if not a.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(a.res, a.ddim_steps, sd, "bounded sample, not a full stamp")
@@ -458,35 +540,13 @@ def main():
         extras = extra_measurements(model, sd)
 
     if rank == 0:
-        lat_sorted = sorted(lat_ms)
-        cfg_idx = {(1, 512, 20): 1, (8, 512, 20): 2, (1, 256, 8): 4}.get((a.batch, a.res, a.ddim_steps))
-        if (a.batch, a.res, a.ddim_steps, world) == (8, 512, 20, 8):
-            cfg_idx = 3  # batch 64 = 8 stamps on each of 8 GPUs, one gather of the decoded patches to rank 0
-        cfg_name = f"BASELINE.json configs[{cfg_idx}]" if cfg_idx is not None else "not a BASELINE.json configuration"
-        if world > 1 and cfg_idx in (1, 2):
-            cfg_name += f" per GPU x {world} GPUs (weak scaling)"
-        if cfg_idx == 4:
-            cfg_name += " workload in fp16 (the fp8 variant is selected with DTP_FP8=1)"
-        line = {
-            "metric": "512x512 inpaint stamps/sec @20 DDIM steps" if (a.res, a.ddim_steps) == (512, 20) else
-                      f"{a.res}x{a.res} inpaint stamps/sec @{a.ddim_steps} DDIM steps",
-            "value": n_total * a.steps / elapsed, "unit": "stamps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f8e4m3 attention" + (" + linear" if model.fp8_linear else "") + " + f16") if model.fp8_attention else "f16", "data": "synthetic",
-            "config": {"workload": f"{cfg_name}: {a.batch} x {a.res}x{a.res} RGBA stamp(s) per GPU, "
-                                   f"{a.ddim_steps} DDIM steps = {a.ddim_steps - 1} UNet evals (reference quirk), 3 guidance branches, "
-                                   "cfg 2.0 / tg 1.0 / tg_steps = steps / context_pad 150, SD-1.5-inpaint UNet + LoRA merged + "
-                                   "AutoencoderKL with seeded synthetic weights, conditioning cached",
-                       "stamps_per_gpu_per_step": a.batch, "resolution": a.res, "ddim_steps": a.ddim_steps,
-                       "unet_evals": info["unet_evals"], "graph_nodes": info["graph_nodes"],
-                       "gather": (f"{'rccl' if backend == 'nccl' else backend}: one gather of the u8 patches into a preallocated "
-                                  f"[{n_total}, {a.res}, {a.res}, 3] buffer on rank 0, inside the timed region") if distributed else "none (1 GPU)",
-                       "ranks_launched_by": "bench.py (launch_ranks)" if os.environ.get("DTP_BENCH_WEIGHTS") else ("torch.distributed.run" if distributed else "single process")},
-            "p50_stamp_latency_ms": lat_sorted[len(lat_sorted) // 2], "p95_stamp_latency_ms": lat_sorted[int(len(lat_sorted) * 0.95)],
-            "stage_ms": {"pre+vae_encode_x2": stage[0], "denoise_loop": stage[1], "vae_decode+post": stage[2]},
-            "roofline": roof, "cpu_baseline": cpu, "extra_configs": extras,
-        }
-        print(json.dumps(line), flush=True)
+        line = compose_line(batch=a.batch, res=a.res, ddim_steps=a.ddim_steps, world=world, steps=a.steps, warmup=a.warmup, elapsed=elapsed,
+                            lat_ms=lat_ms, stage=stage, info=info, roof=roof, cpu=cpu, extras=extras, backend=backend, distributed=distributed,
+                            fp8_attention=model.fp8_attention, fp8_linear=model.fp8_linear,
+                            launched_by_bench=bool(os.environ.get("DTP_BENCH_WEIGHTS")))
+        if detail is not None:
+            line["detail_file"] = write_detail(a.detail, dict(line=line, **detail))
+        print(emit(line), flush=True)
     D.barrier()
 
 
