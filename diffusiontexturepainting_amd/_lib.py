@@ -99,9 +99,12 @@ SYMBOLS = {
     "dtp_op_measure_peaks": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dtp_op_reduce_groupnorm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "dtp_op_xattn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "dtp_op_reduce_groupnorm_cx": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "dtp_op_xattn_ct": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "dtp_op_gn_fold_weights": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "dtp_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
     "dtp_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp]),
+    "dtp_op_attention_dma": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _i, _vp]),
     "dtp_op_softmax_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
     "dtp_op_attention_fp8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _f, _f, _vp]),
     "dtp_op_dilate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

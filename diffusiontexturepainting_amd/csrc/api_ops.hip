@@ -185,20 +185,23 @@ int dtp_op_groupnorm_apply(const void* x, int ldx, void* y, int ldy, const float
   return dtp_launch_groupnorm_apply((const f16*)x, ldx, (f16*)y, ldy, gamma, beta, partial, nchunk, B, HW, C, groups, eps, silu, (hipStream_t)s);
 }
 
-int dtp_op_reduce_groupnorm(const float* part, int splits, const float* bias, const void* resid, void* conv_out, void* y, const float* gamma,
-                            const float* beta, int B, int HW, int C, int groups, float eps, int silu, dtp_stream s) {
+int dtp_op_reduce_groupnorm_cx(const float* part, int splits, const float* bias, const void* resid, void* conv_out, void* y, const float* gamma,
+                               const float* beta, int B, int HW, int C, int groups, float eps, int silu, int cx, dtp_stream s) {
   std::lock_guard<std::mutex> lk(g_ops_mu);
   int rc = ops_init();
   if (rc) return rc;
   rc = ops_ws(dtp_groupnorm_ws_bytes(B, HW, C, groups));
   if (rc) return rc;
-  // $DTP_RGN_CX = Cx (read per call, parity tests only): the slabs hold the FIRST Cx channels ([splits][B*HW][Cx]); channels >= Cx are already in
-  // conv_out (the other half of a zero-copy concatenation) -- the round-5 form of the launch (engine.hip Builder::claim_reduce)
-  int cx = C;
-  if (const char* e = getenv("DTP_RGN_CX")) cx = atoi(e);
-  if (cx <= 0 || cx > C) cx = C;
+  // cx < C: the slabs hold the FIRST cx channels ([splits][B*HW][cx]); channels >= cx are already in conv_out (the other half of a
+  // zero-copy concatenation) -- the round-5 form of the launch (engine.hip Builder::claim_reduce)
+  if (cx <= 0 || cx > C) { dtp_set_error("reduce_groupnorm: cx %d outside (0, C = %d]", cx, C); return DTP_ERR_ARG; }
   return dtp_launch_reduce_groupnorm(part, splits, (long long)B * HW * cx, cx, bias, (const f16*)resid, cx, (f16*)conv_out, C, (f16*)y, C, gamma, beta, B, HW, C,
                                      groups, eps, silu, g_ops.ws, (hipStream_t)s, cx);
+}
+
+int dtp_op_reduce_groupnorm(const float* part, int splits, const float* bias, const void* resid, void* conv_out, void* y, const float* gamma,
+                            const float* beta, int B, int HW, int C, int groups, float eps, int silu, dtp_stream s) {
+  return dtp_op_reduce_groupnorm_cx(part, splits, bias, resid, conv_out, y, gamma, beta, B, HW, C, groups, eps, silu, C, s);
 }
 
 int dtp_op_gn_fold_weights(const void* x, const void* W, int ldw, const float* bias, const float* gamma, const float* beta, int B, int HW, int C,
@@ -215,8 +218,8 @@ int dtp_op_gn_fold_weights(const void* x, const void* W, int ldw, const float* b
                                     rows, (hipStream_t)s);
 }
 
-int dtp_op_xattn(const void* X, const void* W1, const float* b1, const float* lns1, const float* st_in, int st_parts, const void* W2, const float* b2,
-                 const void* R, void* Y, float* st_out, int S, int C, int N, int sm_valid, float ln_eps, dtp_stream s) {
+int dtp_op_xattn_ct(const void* X, const void* W1, const float* b1, const float* lns1, const float* st_in, int st_parts, const void* W2, const float* b2,
+                    const void* R, void* Y, float* st_out, int S, int C, int N, int sm_valid, float ln_eps, int ct, dtp_stream s) {
   std::lock_guard<std::mutex> lk(g_ops_mu);
   int rc = ops_init();
   if (rc) return rc;
@@ -227,9 +230,13 @@ int dtp_op_xattn(const void* X, const void* W1, const float* b1, const float* ln
   p.st_in = st_in; p.st_parts = st_parts; p.st_rows = N * S; p.ln_eps = ln_eps;
   p.W2 = (const f16*)W2; p.w2_bs = (long long)((C + 127) / 128 * 128) * 128; p.b2 = b2; p.R = (const f16*)R; p.ldr = C;
   p.Y = (f16*)Y; p.ldy = C; p.st_out = st_out; p.S = S; p.C = C; p.N = N; p.sm_valid = sm_valid; p.zero = (const f16*)g_ops.zero;
-  // column tiles per workgroup: the launcher's rule, or $DTP_XATTN_CT (read per call: the parity tests walk through several values)
-  if (const char* e = getenv("DTP_XATTN_CT")) p.ct = atoi(e);
+  p.ct = ct;  // column tiles per workgroup; < 1: the launcher's rule
   return dtp_launch_xattn(p, (hipStream_t)s);
+}
+
+int dtp_op_xattn(const void* X, const void* W1, const float* b1, const float* lns1, const float* st_in, int st_parts, const void* W2, const float* b2,
+                 const void* R, void* Y, float* st_out, int S, int C, int N, int sm_valid, float ln_eps, dtp_stream s) {
+  return dtp_op_xattn_ct(X, W1, b1, lns1, st_in, st_parts, W2, b2, R, Y, st_out, S, C, N, sm_valid, ln_eps, 0, s);
 }
 
 int dtp_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int rows, int C,
@@ -246,6 +253,19 @@ int dtp_op_attention(const void* Q, const void* K, const void* V, void* O, int l
   p.qbs = qbs; p.kbs = kbs; p.vbs = vbs; p.obs = obs;
   p.scale = scale;
   return dtp_launch_attention(p, (hipStream_t)s);
+}
+
+int dtp_op_attention_dma(const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo, int B, int H,
+                         int Sq, int Skv, int D, int64_t qbs, int64_t kbs, int64_t vbs, int64_t obs, float scale, int nw, dtp_stream s) {
+  AttnParams p;
+  p.Q = (const f16*)Q; p.K = (const f16*)K; p.V = (const f16*)V; p.O = (f16*)O;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.D = D;
+  p.qbs = qbs; p.kbs = kbs; p.vbs = vbs; p.obs = obs;
+  p.scale = scale;
+  if (nw != 0 && nw != 4 && nw != 8) { dtp_set_error("attention_dma: nw %d (0 = the launcher's rule, 4, 8)", nw); return DTP_ERR_ARG; }
+  if (!Q && !K && !V && !O) return dtp_attention_dma_supported(p) ? DTP_OK : DTP_ERR_ARG;  // a query: would the kernel take this problem?
+  return dtp_launch_attention_dma(p, (hipStream_t)s, nw);
 }
 
 int dtp_op_attention_fp8(const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo, int B, int H,

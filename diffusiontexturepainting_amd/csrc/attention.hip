@@ -377,8 +377,8 @@ int dtp_launch_attention(const AttnParams& pin, hipStream_t s) {
   // round 5: the long full-tile launches (UNet levels 0 / 1) run on the LDS-DMA kernel (attn_dma.hip); $DTP_ATTN_DMA=0 keeps them here (A/B)
   static const int dma_env = [] { const char* e = getenv("DTP_ATTN_DMA"); return e ? atoi(e) : 1; }();
   // (from 512 keys on: measured inside a stamp, S = 4096 -3 %, S = 1024 -11 ... -16 %, S = 256 +-1 %; the kernel itself also takes 128 / 256)
-  const char* const dma_min_env = getenv("DTP_ATTN_DMA_MIN_S");  // (read per call: the parity tests drive the kernel on short sequences too)
-  const int dma_min = dma_min_env ? atoi(dma_min_env) : 512;
+  // ($DTP_ATTN_DMA_MIN_S: A/B switch, read once; the parity tests drive the kernel on short sequences through dtp_op_attention_dma)
+  static const int dma_min = [] { const char* e = getenv("DTP_ATTN_DMA_MIN_S"); return e ? atoi(e) : 512; }();
   if (dma_env && p.Skv >= dma_min && dtp_attention_dma_supported(p)) return dtp_launch_attention_dma(p, s);
   dim3 grid((p.Sq + 127) / 128, p.H, p.B), block(256);
   static const int cus = [] {

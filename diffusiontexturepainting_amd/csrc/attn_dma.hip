@@ -539,7 +539,13 @@ bool dtp_attention_dma_supported(const AttnParams& p) {
   return true;
 }
 
-int dtp_launch_attention_dma(const AttnParams& p, hipStream_t s) {
+// nw_force: 0 = the rule below, 4 / 8 = that many waves per workgroup (d = 40 only has the eight-wave build; parity tests)
+// Inputs must be FINITE: at d = 40 the third K k-step and V columns 48..63 deliberately over-read into the next key's row / the other
+// image / the zeroed tail, and that over-read is multiplied by zero Q' columns or lands in O^T rows that are never stored -- 0 x Inf
+// is NaN, so a single Inf / NaN in one K row also poisons the score of the key in front of it (check_finite then localises
+// differently from attention_kernel).  The K / V range check (2^30 bytes) above is the guard on the 32-bit voff + soff of the DMA;
+// Q and O are addressed with plain 64-bit pointers.
+int dtp_launch_attention_dma(const AttnParams& p, hipStream_t s, int nw_force) {
   if (!dtp_attention_dma_supported(p)) { dtp_set_error("attention (LDS-DMA kernel): unsupported problem D=%d Skv=%d", p.D, p.Skv); return DTP_ERR_ARG; }
   static const int cus = [] {
     int dev = 0;
@@ -548,7 +554,7 @@ int dtp_launch_attention_dma(const AttnParams& p, hipStream_t s) {
   }();
   // eight-wave workgroups only when every CU still gets several of them ($DTP_ATTN_NW8=0/1 forces it off / on)
   static const int nw8_env = [] { const char* e = getenv("DTP_ATTN_NW8"); return e ? atoi(e) : -1; }();
-  const bool nw8 = nw8_env >= 0 ? nw8_env != 0 : (long long)((p.Sq + 255) / 256) * p.H * p.B >= 8LL * cus;
+  const bool nw8 = nw_force ? nw_force == 8 : nw8_env >= 0 ? nw8_env != 0 : (long long)((p.Sq + 255) / 256) * p.H * p.B >= 8LL * cus;
   if (p.D == 40) return nw8 ? launch<40, 4, 8>(p, s) : launch<40, 4, 4>(p, s);
 #ifdef DTP_EXPERIMENTAL
   if (p.D == 160) return launch<160, 3, 4>(p, s);  // levels 2-3 (S = 256 / 64): one 128-query workgroup per CU at most, the whole launch is latency

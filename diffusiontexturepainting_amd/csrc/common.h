@@ -272,7 +272,7 @@ struct AttnParams {
 int dtp_launch_attention(const AttnParams& p, hipStream_t s);
 // attn_dma.hip: K / V by LDS-DMA, V^T fragments by transpose reads (d = 40 / 80, Skv a multiple of 64); dtp_launch_attention dispatches
 bool dtp_attention_dma_supported(const AttnParams& p);
-int dtp_launch_attention_dma(const AttnParams& p, hipStream_t s);
+int dtp_launch_attention_dma(const AttnParams& p, hipStream_t s, int nw_force = 0);
 // attention_fp8.hip: the same contraction on the fp8 (e4m3) MX MFMA; q_scale / v_scale = per-tensor scales (powers of two)
 int dtp_launch_attention_fp8(const AttnParams& p, float q_scale, float v_scale, hipStream_t s);
 

@@ -363,6 +363,49 @@ T Builder::alloc(int B, int H, int W, int C) {
 }
 void Builder::release(const T& t) { ctx_pool_put(c, t.p); }
 
+// Which conv outputs can carry their consumer GroupNorm's statistics (GF_GNSTATS of the two-n-tile convws builds)?  ONE predicate for
+// Builder::claim_stats (which re-pushes the conv with the flag) and for tune_gemm (which credits such a candidate with the statistics
+// pass it saves) -- round-5 advisor: the two had repeated parts of each other's conditions (chunk cap, channels-per-group range) and
+// could drift apart.  `p` is the UNSPLIT problem.  What the shape cannot tell is the consumer: an output view inside a concatenation
+// buffer (ldc > N) is claimed when the next GroupNorm runs over that view alone (down path: the skip slot IS the layer output) and not
+// when it runs over the whole concatenation (up path); the tuner's credit stays a shape-level estimate.
+bool dtp_conv_output_can_carry_gn_stats(const GemmParams& p) {
+  const int keep = GF_BIAS | GF_RESID | GF_CONV3 | GF_UPS2 | GF_MFAST;
+  if ((p.flags & ~keep) || !(p.flags & GF_CONV3) || p.batch > 1) return false;
+  if ((p.N % 32) || p.N / 32 < 4 || p.N / 32 > 64) return false;
+  // every block of the consumer re-reads its image's whole partials table (chunks x 32 x 8 bytes): beyond ~1k chunks (the VAE's 512^2 and
+  // 256^2 maps: 1 MB per image) that is more traffic than the statistics pass it replaces (round-4 advisor) -- those keep the pass
+  if ((p.Ho & 7) || (p.Wo & 15) || 2 * (p.Ho / 8) * (p.Wo / 16) > 1024) return false;
+  return true;
+}
+
+// A pool block that overlaps none of `ranges` (operands some launch still reads while the block is being written).  The pool hands out
+// whatever fits -- also a block an operand was released from a moment ago, because the Builder releases tensors as soon as their last
+// consumer is PUSHED, not run; a launch that both reads such an operand and writes the new block would race with itself (round-4 / 5
+// advisor: GroupNorm output vs the claimed reduce's residual, statistics partials vs the conv's operands).  Overlapping blocks are set
+// aside for the duration of the search and returned.
+struct MemRange { const void* p; size_t bytes; };
+static void* pool_get_clear_of(Ctx* c, size_t need, const std::vector<MemRange>& ranges, int attempts = 6) {
+  std::vector<void*> aside;
+  void* got = nullptr;
+  for (int attempt = 0; attempt < attempts; ++attempt) {
+    void* pp = nullptr;
+    if (ctx_pool_get(c, need, &pp) != DTP_OK) break;
+    bool hit = false;
+    for (const MemRange& r : ranges)
+      if (r.p && r.bytes && (const char*)pp < (const char*)r.p + r.bytes && (const char*)r.p < (const char*)pp + need) { hit = true; break; }
+    if (!hit) { got = pp; break; }
+    aside.push_back(pp);
+  }
+  for (void* q : aside) ctx_pool_put(c, q);
+  return got;
+}
+// the operands a (re-pushed) GEMM / conv launch reads
+static std::vector<MemRange> gemm_operand_ranges(const GemmParams& gp, long long images) {
+  const size_t in_bytes = (gp.flags & GF_CONV3) ? (size_t)images * gp.Hi * gp.Wi * gp.lda * sizeof(f16) : (size_t)gp.M * gp.lda * sizeof(f16);
+  return {{gp.A, in_bytes}, {gp.A2, gp.A2 ? (size_t)gp.M * gp.lda2 * sizeof(f16) : 0}, {gp.R, gp.R ? (size_t)gp.M * gp.ldr * sizeof(f16) : 0}};
+}
+
 // The producer of x was a split-K conv whose reduce has not run yet: take the reduce over (the GroupNorm-side kernel sums the slabs
 // and writes x itself).  Re-pushes the conv with GF_NOREDUCE and returns its parameters.
 bool Builder::claim_reduce(const T& x, GemmParams& gp, int& bias_step_off, bool allow_concat) {
@@ -394,35 +437,17 @@ bool Builder::claim_reduce(const T& x, GemmParams& gp, int& bias_step_off, bool 
 bool Builder::claim_stats(const T& x, float** partials, int* nchunk) {
   static const bool off = [] { const char* e = getenv("DTP_NO_GN_EPILOGUE"); return e && e[0] && e[0] != '0'; }();
   const LastGemm lg = prog->last_gemm;
-  const int keep = GF_BIAS | GF_RESID | GF_CONV3 | GF_UPS2 | GF_MFAST;
   if (off || !lg.valid || lg.tile < DTP_TILE_WS0 + 2 || !dtp_is_ws_tile(lg.tile) || lg.p.splits != 1 || (f16*)lg.p.C != x.p || lg.p.ldc != x.ld ||
-      lg.p.M != (int)x.rows() || lg.p.N != x.C || (lg.p.flags & ~keep) || (x.C % 32) || x.C / 32 < 4 || x.C / 32 > 64)
+      lg.p.M != (int)x.rows() || lg.p.N != x.C || !dtp_conv_output_can_carry_gn_stats(lg.p))
     return false;
   GemmParams gp = lg.p;
   const int chunks = 2 * (gp.Ho / 8) * (gp.Wo / 16);
-  // every block of the consumer re-reads its image's whole partials table (chunks x 32 x 8 bytes): beyond ~1k chunks (the VAE's 512^2 and
-  // 256^2 maps: 1 MB per image) that is more traffic than the statistics pass it replaces (round-4 advisor) -- those keep the pass
-  if (chunks > 1024) return false;
   // The conv's input (and residual / shortcut operand) may already be back in the pool -- gn_conv3 releases it before its consumer is
   // built -- and the pool would happily hand that very block out for the partials, which the re-pushed conv WRITES while other
-  // workgroups still read the operand (round-4 advisor: a latent aliasing race).  Blocks that overlap an operand are set aside.
+  // workgroups still read the operand (round-4 advisor: a latent aliasing race): pool_get_clear_of.
   const size_t need = (size_t)x.B * chunks * 32 * 2 * sizeof(float);
-  void* pp = nullptr;
-  std::vector<void*> aside;
-  auto overlaps = [&](const void* q, size_t bytes) {
-    const char* a = (const char*)q;
-    auto hit = [&](const void* o, size_t ob) { return o && a < (const char*)o + ob && (const char*)o < a + bytes; };
-    const size_t in_bytes = (size_t)x.B * gp.Hi * gp.Wi * gp.lda * sizeof(f16);
-    return hit(gp.A, in_bytes) || hit(gp.A2, (size_t)gp.M * gp.lda2 * sizeof(f16)) || hit(gp.R, (size_t)gp.M * gp.ldr * sizeof(f16));
-  };
-  bool ok = false;
-  for (int attempt = 0; attempt < 4; ++attempt) {
-    if (ctx_pool_get(c, need, &pp) != DTP_OK) break;
-    if (!overlaps(pp, need)) { ok = true; break; }
-    aside.push_back(pp);
-  }
-  for (void* q : aside) ctx_pool_put(c, q);
-  if (!ok) return false;
+  void* pp = pool_get_clear_of(c, need, gemm_operand_ranges(gp, x.B), 4);
+  if (!pp) return false;
   gp.flags |= GF_GNSTATS;
   gp.st_out = (float*)pp;
   gp.gn_cpg = x.C / 32;
@@ -446,16 +471,11 @@ int Builder::gn(const T& x, const NormW& n, float eps, bool silu, T& y) {
   // whole-tensor case never showed it; over a concatenation the pitches differ and the stamp stopped being reproducible.)  Blocks
   // that overlap the residual are set aside while y is taken.
   {
-    std::vector<void*> aside;
-    const char* r0 = (claimed && (gp.flags & GF_RESID)) ? (const char*)gp.R : nullptr;
-    const size_t rbytes = r0 ? (size_t)gp.M * gp.ldr * sizeof(f16) : 0, ybytes = (size_t)x.B * x.H * x.W * x.C * sizeof(f16);
-    for (int attempt = 0; attempt < 6; ++attempt) {
-      y = alloc(x.B, x.H, x.W, x.C);
-      if (!y.p || !r0 || !((const char*)y.p < r0 + rbytes && r0 < (const char*)y.p + ybytes)) break;
-      aside.push_back(y.p);
-      y.p = nullptr;
-    }
-    for (void* q : aside) ctx_pool_put(cc, q);
+    std::vector<MemRange> busy;
+    if (claimed && (gp.flags & GF_RESID)) busy.push_back({gp.R, (size_t)gp.M * gp.ldr * sizeof(f16)});
+    y = T();
+    y.B = x.B; y.H = x.H; y.W = x.W; y.C = x.C; y.ld = x.C;
+    y.p = (f16*)pool_get_clear_of(cc, (size_t)x.B * x.H * x.W * x.C * sizeof(f16), busy);
     if (!y.p) { dtp_set_error("gn: no output block clear of the claimed reduce's residual"); return DTP_ERR_HIP; }
   }
   cc->ws_need = std::max(cc->ws_need, dtp_groupnorm_ws_bytes(x.B, x.H * x.W, x.C, 32));
@@ -809,8 +829,9 @@ static int tune_gemm(Ctx* c, GemmParams& p, int* tile_out) {
     // Round 5 found the level-0 long-shortcut convs on the halo kernel by 1-2 us -- and 76 statistics launches per stamp behind them
     // (switched by hand in the shipped table: -0.4 % at batch 1; at batch 8 the halo kernel's lead is larger than the pass).  The
     // statistics-capable candidate is credited with that pass when its output is one claim_stats would take.
-    if (ws_any && !dtp_is_ws_tile(bt) && !(p.flags & ~(GF_BIAS | GF_RESID | GF_CONV3 | GF_UPS2 | GF_MFAST)) && (p.N % 32) == 0 && p.N / 32 >= 4 &&
-        p.N / 32 <= 64 && 2 * (p.Ho / 8) * (p.Wo / 16) <= 1024) {
+    // (the tune key does not know the consumer: an output of such a shape is followed by a GroupNorm everywhere in these networks --
+    // conv_out has N = 4 / 3, which the predicate excludes -- but in the up path that GroupNorm runs over a concatenation and cannot claim)
+    if (ws_any && !dtp_is_ws_tile(bt) && dtp_conv_output_can_carry_gn_stats(p)) {
       const float stats_ms = 0.005f + (float)((double)p.M * p.N * 2.0 / 4.0e12 * 1e3);  // dispatch floor + the tensor once at ~4 TB/s
       for (const Cand& cd : cands)
         if (cd.sp == 1 && (cd.tile == DTP_TILE_WS0 + 2 || cd.tile == DTP_TILE_WS0 + 3) && cd.ms - stats_ms < best) {
@@ -1019,8 +1040,12 @@ int Builder::gn_conv3(const T& x, const NormW& n, float eps, const ConvW& w, con
   const size_t slab_bytes = claimed ? ((dtp_gemm_workspace_bytes(gp) + 255) & ~(size_t)255) : 0;
   // the partial sums outlive the statistics launch (the conv's workgroups read them while other workgroups may already write
   // split-K slabs into the shared workspace): they get their own planned buffer
-  void* pp = nullptr;
-  RC(ctx_pool_get(cc, dtp_groupnorm_ws_bytes(x.B, HW, C, 32), &pp));
+  // (the claimed reduce's residual may be back in the pool already and the reduce + statistics launch that writes the partials still reads
+  // it: round-5 advisor, the same aliasing as in gn() / claim_stats)
+  std::vector<MemRange> busy;
+  if (claimed && (gp.flags & GF_RESID)) busy.push_back({gp.R, (size_t)gp.M * gp.ldr * sizeof(f16)});
+  void* pp = pool_get_clear_of(cc, dtp_groupnorm_ws_bytes(x.B, HW, C, 32), busy);
+  if (!pp) { dtp_set_error("gn_conv3: no partials block clear of the claimed reduce's residual"); return DTP_ERR_HIP; }
   float* partials = (float*)pp;
   cc->ws_need = std::max(cc->ws_need, slab_bytes);
   const T xx = x;

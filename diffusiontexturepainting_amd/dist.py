@@ -107,7 +107,11 @@ def gather_patches(local, n_total, rank, world, dst=0):
     global _gatherers_group
     if world == 1 and not dist.is_initialized():
         return local
-    group = dist.group.WORLD  # (the public handle of the default group; world > 1 without an initialised group raises inside torch)
+    if not dist.is_initialized():
+        # (round-5 advisor: dist.group.WORLD is simply None without a group -- the failure used to surface inside the first collective)
+        raise RuntimeError(f"gather_patches: world={world} but torch.distributed has no initialised process group "
+                           "(call diffusiontexturepainting_amd.dist.init_from_env or dist.init_process_group first)")
+    group = dist.group.WORLD  # the public handle of the default group
     if _gatherers_group is not group:
         _gatherers.clear()
         _gatherers_group = group

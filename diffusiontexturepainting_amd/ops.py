@@ -204,34 +204,24 @@ def reduce_groupnorm(part, gamma, beta, bias=None, resid=None, groups=32, eps=1e
     sp, b, hw, cx = part.shape
     c = cx + (skip.shape[-1] if skip is not None else 0)
     out, y = torch.empty(b, hw, c, dtype=torch.float16, device=part.device), torch.empty(b, hw, c, dtype=torch.float16, device=part.device)
-    import os
-    old = os.environ.get("DTP_RGN_CX")
-    try:
-        if skip is not None:
-            out[..., cx:] = skip
-            os.environ["DTP_RGN_CX"] = str(cx)  # (read per call by dtp_op_reduce_groupnorm: the C ABI keeps its round-2 signature)
-        else:
-            os.environ.pop("DTP_RGN_CX", None)
-        check(lib.dtp_op_reduce_groupnorm(ptr(part), sp, ptr(bias), ptr(resid), ptr(out), ptr(y), ptr(gamma), ptr(beta), b, hw, c, groups, eps, int(silu),
-                                          _stream()), "reduce_groupnorm")
-    finally:
-        if old is None:
-            os.environ.pop("DTP_RGN_CX", None)
-        else:
-            os.environ["DTP_RGN_CX"] = old
+    if skip is not None:
+        out[..., cx:] = skip
+    check(lib.dtp_op_reduce_groupnorm_cx(ptr(part), sp, ptr(bias), ptr(resid), ptr(out), ptr(y), ptr(gamma), ptr(beta), b, hw, c, groups, eps, int(silu), cx,
+                                         _stream()), "reduce_groupnorm")
     return out, y
 
 
-def xattn(x, w1, b1, lns1, st_in, w2, b2, n_samples, sm_valid=14, ln_eps=1e-5, row_stats=False):
+def xattn(x, w1, b1, lns1, st_in, w2, b2, n_samples, sm_valid=14, ln_eps=1e-5, row_stats=False, ct=0):
     """Fused cross-attention GEMM pair (xattn.hip): x f16 [N*S, C]; w1 f16 [N*128, C]; b1 / lns1 f32 [N*128]; st_in f32 [parts, N*S, 2];
-    w2 f16 [N*roundup(C,128), 128]; b2 f32 [C] -> y f16 [N*S, C] (and the [ceil(C/128), N*S, 2] row-statistics partials)."""
+    w2 f16 [N*roundup(C,128), 128]; b2 f32 [C] -> y f16 [N*S, C] (and the [ceil(C/128), N*S, 2] row-statistics partials).
+    ct: 128-column tiles per workgroup (0 = the launcher's rule)."""
     lib = _lib.load()
     rows, c = x.shape
     s = rows // n_samples
     y = torch.empty_like(x)
     st = torch.zeros((c + 127) // 128, rows, 2, dtype=torch.float32, device=x.device) if row_stats else None
-    check(lib.dtp_op_xattn(ptr(x), ptr(w1), ptr(b1), ptr(lns1), ptr(st_in), st_in.shape[0], ptr(w2), ptr(b2), ptr(x), ptr(y), ptr(st), s, c, n_samples,
-                           sm_valid, ln_eps, _stream()), "xattn")
+    check(lib.dtp_op_xattn_ct(ptr(x), ptr(w1), ptr(b1), ptr(lns1), ptr(st_in), st_in.shape[0], ptr(w2), ptr(b2), ptr(x), ptr(y), ptr(st), s, c, n_samples,
+                              sm_valid, ln_eps, int(ct), _stream()), "xattn")
     return (y, st) if row_stats else y
 
 
@@ -267,6 +257,26 @@ def attention(q, k, v, heads, scale=None):
     scale = scale if scale is not None else d ** -0.5
     check(lib.dtp_op_attention(ptr(q), ptr(k), ptr(v), ptr(o), q.stride(1), k.stride(1), v.stride(1), o.stride(1), b, heads,
                                sq, skv, d, q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, _stream()), "attention")
+    return o
+
+
+def attention_dma_supported(sq, skv, heads, d):
+    """Would attn_dma_kernel take a contiguous [B, S, heads * d] problem?  (d in {40, 80} in the product build.)"""
+    lib = _lib.load()
+    c = heads * d
+    return lib.dtp_op_attention_dma(None, None, None, None, c, c, c, c, 1, heads, sq, skv, d, sq * c, skv * c, skv * c, sq * c, 1.0, 0, None) == 0
+
+
+def attention_dma(q, k, v, heads, scale=None, nw=0):
+    """attention() forced onto the LDS-DMA kernel (attn_dma.hip) whatever the sequence length; nw = waves per workgroup (0 = rule, 4, 8)."""
+    lib = _lib.load()
+    b, sq, c = q.shape
+    skv = k.shape[1]
+    d = c // heads
+    o = torch.empty(b, sq, c, dtype=torch.float16, device=q.device)
+    scale = scale if scale is not None else d ** -0.5
+    check(lib.dtp_op_attention_dma(ptr(q), ptr(k), ptr(v), ptr(o), q.stride(1), k.stride(1), v.stride(1), o.stride(1), b, heads,
+                                   sq, skv, d, q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, int(nw), _stream()), "attention_dma")
     return o
 
 

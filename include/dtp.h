@@ -246,12 +246,19 @@ int dtp_op_measure_peaks(double* mfma_f16_tflops, double* hbm_copy_gbs);
  * behind a conv); one launch for HW <= 256, reduce-in-statistics + apply above */
 int dtp_op_reduce_groupnorm(const float* part, int splits, const float* bias, const void* resid, void* conv_out, void* y, const float* gamma,
                             const float* beta, int B, int HW, int C, int groups, float eps, int silu, dtp_stream s);
+/* the same launch over a zero-copy concatenation (engine Builder::claim_reduce): the slabs (bias, resid) hold the FIRST cx channels
+ * ([splits][B*HW][cx]); channels [cx, C) are already in conv_out; the GroupNorm runs over all C.  cx == C is the call above. */
+int dtp_op_reduce_groupnorm_cx(const float* part, int splits, const float* bias, const void* resid, void* conv_out, void* y, const float* gamma,
+                               const float* beta, int B, int HW, int C, int groups, float eps, int silu, int cx, dtp_stream s);
 /* the two grouped GEMMs of the algebraically fused cross-attention (attn2 of BasicTransformerBlock against 14 context tokens) as ONE
  * launch: Y = softmax_16(LN(X) W1^T + b1) W2^T + b2 + R per sample.  X / R / Y f16 [N*S][C]; W1 f16 [N][128][C] (LayerNorm gamma
  * folded in), b1 / lns1 f32 [N][128]; st_in f32 [st_parts][N*S][2] = per-row (sum, sumsq) partials of X; W2 f16 [N][roundup(C,128)][128];
  * st_out f32 [ceil(C/128)][N*S][2] (or null) = the same partials of Y for the next LayerNorm-folded GEMM */
 int dtp_op_xattn(const void* X, const void* W1, const float* b1, const float* lns1, const float* st_in, int st_parts, const void* W2, const float* b2,
                  const void* R, void* Y, float* st_out, int S, int C, int N, int sm_valid, float ln_eps, dtp_stream s);
+/* the same with an explicit number of 128-column tiles per workgroup (ct >= 1; ct < 1 = the launcher's rule, i.e. the call above) */
+int dtp_op_xattn_ct(const void* X, const void* W1, const float* b1, const float* lns1, const float* st_in, int st_parts, const void* W2, const float* b2,
+                    const void* R, void* Y, float* st_out, int S, int C, int N, int sm_valid, float ln_eps, int ct, dtp_stream s);
 /* GroupNorm (no activation) folded into the Linear / 1x1 conv that consumes it (Transformer2DModel: norm -> proj_in): from x f16
  * [B][HW][C] and the packed weights W f16 [rows][ldw] (+ bias[Nout]) compute per-sample Wout f16 [B][rows][ldw] = W diag(gamma * rstd_b)
  * and bias_out f32 [B][rows] = bias + W (beta - mean_b * rstd_b * gamma), rows = roundup(Nout, 128): proj(GN(x_b)) == Wout_b x_b + bias_out_b */
@@ -264,6 +271,12 @@ int dtp_op_attention(const void* Q, const void* K, const void* V, void* O, int l
 /* The same attention with both contractions on the fp8 (OCP e4m3) block-scaled MFMA (BASELINE configs[4]): q / k / v / o stay f16 in
  * memory, tiles are quantised on their way into LDS.  q_scale, v_scale: per-tensor scales (powers of two; Q is stored as
  * Q*q_scale and K as K/q_scale so the scores are unchanged, V as V/v_scale).  D %% 8 == 0, D %% 64 != 0, D <= 184. */
+/* the self-attention launch forced onto attn_dma_kernel (K / V by LDS-DMA; the stamp's dispatcher uses it from 512 keys on), whatever the
+ * sequence length; nw = waves per workgroup (0 = the launcher's rule, 4, 8: d = 40 has both builds).  DTP_ERR_ARG when the kernel does
+ * not take the problem (d not in {40, 80}, Skv % 64, Skv < 128, alignment); with all four pointers null the call only answers that
+ * question.  Inputs must be finite (see dtp_launch_attention_dma). */
+int dtp_op_attention_dma(const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo, int B, int H,
+                         int Sq, int Skv, int D, int64_t qbs, int64_t kbs, int64_t vbs, int64_t obs, float scale, int nw, dtp_stream s);
 int dtp_op_attention_fp8(const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo, int B, int H,
                          int Sq, int Skv, int D, int64_t qbs, int64_t kbs, int64_t vbs, int64_t obs, float scale, float q_scale,
                          float v_scale, dtp_stream s);

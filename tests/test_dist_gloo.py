@@ -105,3 +105,11 @@ def test_single_process_is_passthrough():
     t = torch.arange(6).reshape(2, 3)
     assert D.gather_patches(t, 2, 0, 1) is t
     assert D.max_over_ranks(3.5, torch.device("cpu")) == 3.5
+
+
+def test_gather_without_a_process_group_fails_with_a_clear_message():
+    """world > 1 but nobody initialised torch.distributed: an error that names the missing step, not a None group inside a collective."""
+    import pytest
+    assert not torch.distributed.is_initialized()
+    with pytest.raises(RuntimeError, match="no initialised process group"):
+        D.gather_patches(torch.zeros(1, 4), 2, 0, 2)

@@ -123,7 +123,7 @@ def test_plain_bench_command_with_two_ranks_on_one_gpu():
     line = _run_bench(dict(DTP_BENCH_BACKEND="gloo", DTP_BENCH_SAME_DEVICE="1"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                       "--res", "64", "--ddim-steps", "4", "--batch", "2", "--no-cpu-baseline", "--no-extras", "--no-profile")
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
-    assert abs(line["value"] - 4 * 1e3 / line["ms_per_step"]) / line["value"] < 1e-6  # whole job: 2 ranks x 2 stamps per step
+    assert abs(line["value"] - 4 * 1e3 / line["ms_per_step"]) / line["value"] < 1e-4  # whole job: 2 ranks x 2 stamps per step (6 digits printed)
     assert line["config"]["gather"].startswith("gloo") and line["config"]["ranks_launched_by"].startswith("bench.py")
 
 

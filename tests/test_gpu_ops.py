@@ -42,8 +42,16 @@ def close(got, ref, tol=2e-3):
     assert err <= lim, f"max err {err} > {lim}"
 
 
-@pytest.mark.parametrize("m,n,k", [(300, 320, 320), (4096, 640, 1280), (192, 1280, 2560), (77, 768, 768), (14, 1280, 768)])
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 20, 21, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47])  # shape + 4 * (stages - 2); 16.. = 256-wide tiles; 20 / 21 = 8-wave wide tiles; 32.. = 8-wave (k-split) twins of 0..7; 40.. = loader-wave variants (4 / 8 DMA-only waves)
+GEMM_SHAPES = [(300, 320, 320), (4096, 640, 1280), (192, 1280, 2560), (77, 768, 768), (14, 1280, 768)]
+GEMM_TILES = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 20, 21, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47]  # shape + 4 * (stages - 2); 16.. = 256-wide tiles; 20 / 21 = 8-wave wide tiles; 32.. = 8-wave (k-split) twins of 0..7; 40.. = loader-wave variants (4 / 8 DMA-only waves)
+# round 6: every tile id still runs, the heuristic (-1) on all five shapes, an explicit tile on THREE of them -- always the large one (every
+# pipeline stage in steady state) and two of the four ragged ones, rotating with the tile's position (the full 35 x 5 cross-product was a
+# minute of the driver's GPU leg re-checking the same code paths)
+GEMM_CASES = [(m, n, k, t) for i, t in enumerate(GEMM_TILES) for j, (m, n, k) in enumerate(GEMM_SHAPES)
+              if t == -1 or j == 1 or j == (0, 2, 3, 4)[i % 4] or j == (2, 3, 4, 0)[(i // 4) % 4]]
+
+
+@pytest.mark.parametrize("m,n,k,tile", GEMM_CASES)
 def test_gemm_dense(ops, m, n, k, tile):
     a, w = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5)
     bias = torch.randn(n, generator=torch.Generator().manual_seed(3))
@@ -345,10 +353,8 @@ def test_fused_cross_attention_several_column_tiles_per_workgroup(ops, nb, s, c,
     w1p = torch.cat([ops.pack_linear(w1[b].cuda()) for b in range(nb)], dim=0).contiguous()
     lns = ops.rowsum(w1p, c)
     w2p = torch.cat([ops.pack_linear(w2[b].cuda()) for b in range(nb)], dim=0).contiguous()
-    monkeypatch.setenv("DTP_XATTN_CT", "1")
-    ref_y, ref_st = ops.xattn(x, w1p, b1.reshape(-1).cuda(), lns, st_in, w2p, b2.cuda(), nb, row_stats=True)
-    monkeypatch.setenv("DTP_XATTN_CT", str(ct))
-    got_y, got_st = ops.xattn(x, w1p, b1.reshape(-1).cuda(), lns, st_in, w2p, b2.cuda(), nb, row_stats=True)
+    ref_y, ref_st = ops.xattn(x, w1p, b1.reshape(-1).cuda(), lns, st_in, w2p, b2.cuda(), nb, row_stats=True, ct=1)
+    got_y, got_st = ops.xattn(x, w1p, b1.reshape(-1).cuda(), lns, st_in, w2p, b2.cuda(), nb, row_stats=True, ct=ct)
     assert torch.equal(got_y, ref_y) and torch.equal(got_st, ref_st)
 
 
@@ -417,8 +423,12 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [-1, 5, 8, 10, 16, 19, 20, 21, 32, 34, 37, 39, 40, 42, 45, 47])
-@pytest.mark.parametrize("case", CONV_CASES)
+CONV_TILES = [-1, 5, 8, 10, 16, 19, 20, 21, 32, 34, 37, 39, 40, 42, 45, 47]
+# (round 6, as for test_gemm_dense: the heuristic on every case, an explicit tile on four of the seven, rotating)
+CONV_TILE_CASES = [(c, t) for i, t in enumerate(CONV_TILES) for j, c in enumerate(CONV_CASES) if t == -1 or (j + i) % 7 in (0, 2, 3, 5)]
+
+
+@pytest.mark.parametrize("case,tile", CONV_TILE_CASES)
 def test_conv3x3(ops, case, tile):
     b, h, w, cin, cout, stride, pad, ups, out_hw = case
     if tile in (20, 21) and cout % 8:
@@ -760,24 +770,41 @@ def test_attention_eight_wave_workgroups_on_a_batched_launch(ops):
 @pytest.mark.parametrize("b,sq,skv,heads,d", [(3, 4096, 4096, 8, 40), (3, 1024, 1024, 8, 80), (1, 200, 256, 8, 40), (2, 40, 128, 4, 80),
                                               (1, 1024, 1024, 5, 40), (2, 300, 640, 8, 80), (24, 256, 256, 8, 40), (130, 500, 512, 8, 40),
                                               (3, 256, 256, 8, 160), (3, 64, 64, 8, 160), (1, 200, 320, 8, 160), (2, 64, 128, 3, 160)])
-def test_attention_dma_kernel(ops, b, sq, skv, heads, d, monkeypatch):
-    monkeypatch.setenv("DTP_ATTN_DMA_MIN_S", "0")  # the dispatcher hands the kernel sequences of >= 512 keys only (where it wins)
+def test_attention_dma_kernel(ops, b, sq, skv, heads, d):
     """attn_dma_kernel (round 5: K / V tiles by LDS-DMA, V^T fragments by ds_read_b64_tr_b16, the softmax shift in the MFMA's C operand):
     the UNet's level-0 / level-1 launches at batch 1, ragged query blocks, Sq != Skv, a (batch x heads) count that is not a multiple
     of 8 (the plain block -> (head, query block) map), short sequences (2 tiles: shorter than the DMA ring), many small problems, and a
     launch with >= 8 x CUs 256-query blocks (130 samples x 8 heads x 2: the eight-wave build, one K / V tile staged for 256 queries).
-    The d = 160 cases run on the kernel only in a DTP_EXPERIMENTAL=1 build (it brought nothing at levels 2-3), on attention_kernel otherwise."""
+    The d = 160 cases exist only in a DTP_EXPERIMENTAL=1 build (the kernel brought nothing at levels 2-3) and skip otherwise.  The kernel is
+    called through dtp_op_attention_dma: the stamp's dispatcher hands it sequences of >= 512 keys only (where it wins)."""
+    if not ops.attention_dma_supported(sq, skv, heads, d):
+        assert d == 160, "the product build takes d = 40 / 80 with whole 64-key tiles"
+        pytest.skip("d = 160 on attn_dma_kernel: DTP_EXPERIMENTAL builds only")
     c = heads * d
     q, k, v = rnd(b, sq, c, seed=260), rnd(b, skv, c, seed=261), rnd(b, skv, c, seed=262)
     ref = _attn_ref(q, k, v, heads)
-    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads)
+    got = ops.attention_dma(q.cuda(), k.cuda(), v.cuda(), heads)
+    close(got, ref, tol=3e-3)
+
+
+@pytest.mark.parametrize("nw", [4, 8])
+@pytest.mark.parametrize("sq,skv", [(200, 128), (300, 192), (130, 192), (257, 128), (64, 192)])
+def test_attention_dma_ragged_query_blocks_and_short_key_ranges_on_both_builds(ops, sq, skv, nw):
+    """Round-5 advisor: Sq that is not a multiple of 128 / 256 (the last query block of the four- and of the eight-wave build is ragged:
+    rows >= Sq are computed on clamped addresses and never stored) with Skv = 128 / 192 (2-3 key tiles: shorter than the DMA ring of four
+    slots), d = 40 through BOTH builds.  At d = 40 the kernel over-reads the third K k-step / V columns 48..63 into the next key's
+    row: the reference must still match (the over-read meets zero Q' columns), including for the LAST key (whose over-read leaves the tensor)."""
+    b, heads, d = 2, 8, 40
+    c = heads * d
+    q, k, v = rnd(b, sq, c, seed=290), rnd(b, skv, c, seed=291), rnd(b, skv, c, seed=292)
+    ref = _attn_ref(q, k, v, heads)
+    got = ops.attention_dma(q.cuda(), k.cuda(), v.cuda(), heads, nw=nw)
     close(got, ref, tol=3e-3)
 
 
 @pytest.mark.parametrize("d,s,spike_at,gain", [(40, 1024, 900, 6.0), (80, 512, 70, 5.0), (40, 256, 255, 8.0), (80, 1024, 0, 6.0), (160, 256, 200, 4.0),
                                                (160, 128, 40, 4.0)])
-def test_attention_dma_reference_moves_late_and_peaked_rows(ops, d, s, spike_at, gain, monkeypatch):
-    monkeypatch.setenv("DTP_ATTN_DMA_MIN_S", "0")
+def test_attention_dma_reference_moves_late_and_peaked_rows(ops, d, s, spike_at, gain):
     """The rare branch of attn_dma_kernel: one key dominates every row from a LATER tile on (the reference moves there, O^T and the row
     sums are rescaled, the pending scores re-based), q / k / v as column slices of one fused buffer, queries scaled up so that the
     softmax is peaked (several moves per row).  Full-tensor fp32 reference; spike_at = 0: the dominant key sits in the first tile."""
@@ -788,12 +815,14 @@ def test_attention_dma_reference_moves_late_and_peaked_rows(ops, d, s, spike_at,
     qkv[:, spike_at, c:2 * c] *= gain
     ref = _attn_ref(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], heads)
     g = qkv.cuda()
-    got = ops.attention(g[..., :c], g[..., c:2 * c], g[..., 2 * c:], heads)
+    if not ops.attention_dma_supported(s, s, heads, d):
+        assert d == 160
+        pytest.skip("d = 160 on attn_dma_kernel: DTP_EXPERIMENTAL builds only")
+    got = ops.attention_dma(g[..., :c], g[..., c:2 * c], g[..., 2 * c:], heads)
     close(got, ref, tol=3e-3)
 
 
-def test_attention_dma_very_negative_and_very_positive_scores(ops, monkeypatch):
-    monkeypatch.setenv("DTP_ATTN_DMA_MIN_S", "0")
+def test_attention_dma_very_negative_and_very_positive_scores(ops):
     """Rows whose scores are all far below zero (the first tile must pull the reference DOWN onto the row maximum, or every P underflows)
     and rows whose scores are far above (no fp16 overflow of P): q is a multiple of one direction, k carries a large component along it."""
     b, s, heads, d = 1, 256, 8, 40
@@ -808,7 +837,7 @@ def test_attention_dma_very_negative_and_very_positive_scores(ops, monkeypatch):
     v = torch.randn(b, s, heads, d, generator=g)
     q, k, v = (t.reshape(b, s, c).half() for t in (q, k, v))
     ref = _attn_ref(q, k, v, heads)
-    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads)
+    got = ops.attention_dma(q.cuda(), k.cuda(), v.cuda(), heads)
     close(got, ref, tol=3e-3)
 
 
