@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-CONTRACTION_KERNELS = ("gemm_kernel", "conv_halo_kernel", "gemm_wide_kernel", "xattn_kernel", "lnlin_kernel", "convws_kernel")
+CONTRACTION_KERNELS = ("gemm_kernel", "conv_halo_kernel", "gemm_wide_kernel", "xattn_kernel", "xchain_kernel", "lnlin_kernel", "convws_kernel")
 PMC_TRAFFIC_FILE = "r05_pmc_unet_traffic.json"  # tools/pmc_unet.sh, committed with the sha1 of the kernel sources it was collected on
 
 
@@ -196,7 +196,7 @@ def roofline_record(rows, classes, batch, res, ddim_steps, step_s, peak_tf, peak
     dom = max(gem, key=lambda r: r["ms"])
     g_ms, g_fl, g_n = sum(r["ms"] for r in gem), sum(r["flops"] for r in gem), sum(r["launches"] for r in gem)
     ach = g_fl / (g_ms * 1e-3) / 1e12
-    gn = [r for r in rows if r["kernel"].startswith("gn_")]
+    gn = [r for r in rows if r["kernel"].startswith(("groupnorm", "gn_"))]
     roof = {
         "bound": "mfma", "kernel": "implicit-GEMM conv / linear / fused-attention-linear class (" + " + ".join(k for k in CONTRACTION_KERNELS) + ")",
         "achieved": ach, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16_TFLOPS,

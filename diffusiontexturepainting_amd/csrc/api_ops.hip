@@ -218,6 +218,44 @@ int dtp_op_gn_fold_weights(const void* x, const void* W, int ldw, const float* b
                                     rows, (hipStream_t)s);
 }
 
+int dtp_op_gn_linear(const void* x, const void* W, int ldw, const float* bias, const float* gamma, const float* beta, int B, int HW, int C,
+                     int Nout, int groups, float eps, void* y, float* st_out, int col_ranges, dtp_stream s) {
+  std::lock_guard<std::mutex> lk(g_ops_mu);
+  int rc = ops_init();
+  if (rc) return rc;
+  static bool init = false;
+  if (!init) { dtp_lnlin_init(); init = true; }
+  if (groups != 32) { dtp_set_error("gn_linear: 32 groups (got %d)", groups); return DTP_ERR_ARG; }
+  rc = ops_ws(dtp_groupnorm_ws_bytes(B, HW, C, groups));
+  if (rc) return rc;
+  rc = dtp_launch_groupnorm_stats((const f16*)x, C, g_ops.ws, B, HW, C, groups, nullptr, (hipStream_t)s);
+  if (rc) return rc;
+  GemmParams p = {};
+  p.A = (const f16*)x; p.lda = C; p.W = (const f16*)W; p.ldw = ldw; p.nkb = ldw / 64;
+  p.M = HW; p.N = Nout; p.K = C; p.C = y; p.ldc = Nout;
+  p.bias = bias; p.flags = (bias ? GF_BIAS : 0) | GF_GNAPPLY | (st_out ? GF_ROWSTATS : 0);
+  p.batch = B; p.a_bs = (long long)HW * C; p.c_bs = (long long)HW * Nout; p.w_bs = 0; p.bias_bs = 0;
+  p.st_out = st_out; p.st_rows = B * HW;
+  p.gn_part = g_ops.ws; p.gn_gamma = gamma; p.gn_beta = beta; p.gn_nchunk = dtp_groupnorm_stat_chunks(HW); p.gn_cpg = C / groups; p.gn_eps = eps;
+  p.zero = g_ops.zero;
+  return dtp_launch_lnlin(p, col_ranges >= 1 ? col_ranges : 4, (hipStream_t)s);
+}
+
+int dtp_op_xchain(const void* A, const void* Wo, int ldwo, const float* bo, const void* Y, const void* W1, const float* b1, const float* lns1,
+                  const void* W2, const float* b2, void* Y3, float* st_out, int S, int C, int N, int sm_valid, float ln_eps, dtp_stream s) {
+  std::lock_guard<std::mutex> lk(g_ops_mu);
+  int rc = ops_init();
+  if (rc) return rc;
+  static bool init = false;
+  if (!init) { dtp_xchain_init(); init = true; }
+  XchainParams p = {};
+  p.A = (const f16*)A; p.lda = C; p.Wo = (const f16*)Wo; p.ldwo = ldwo; p.bo = bo; p.Y = (const f16*)Y; p.ldy = C;
+  p.W1 = (const f16*)W1; p.w1_bs = (long long)128 * C; p.b1 = b1; p.lns1 = lns1;
+  p.W2 = (const f16*)W2; p.w2_bs = (long long)((C + 127) / 128 * 128) * 128; p.b2 = b2;
+  p.Y3 = (f16*)Y3; p.ldy3 = C; p.st_out = st_out; p.S = S; p.C = C; p.N = N; p.sm_valid = sm_valid; p.ln_eps = ln_eps;
+  return dtp_launch_xchain(p, (hipStream_t)s);
+}
+
 int dtp_op_xattn_ct(const void* X, const void* W1, const float* b1, const float* lns1, const float* st_in, int st_parts, const void* W2, const float* b2,
                     const void* R, void* Y, float* st_out, int S, int C, int N, int sm_valid, float ln_eps, int ct, dtp_stream s) {
   std::lock_guard<std::mutex> lk(g_ops_mu);

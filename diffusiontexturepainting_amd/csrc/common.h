@@ -118,6 +118,46 @@ static __device__ __forceinline__ void sum_pairs_strided(const float* __restrict
   }
 }
 
+// The same walk with the partial sums added in DOUBLE (round 6, GroupNorm statistics): every partial is an accurately rounded fp32
+// (sum, sum of squares) of one chunk; their total and the final E[x^2] - mean^2 are formed in fp64, so the variance of a group whose
+// mean is hundreds of standard deviations away from zero does not drown in the rounding of fp32 sums (tests/test_gpu_ops.py
+// test_groupnorm_large_group_means; fp64 adds run at the fp32 rate on this chip and there are <= 16 per lane).
+static __device__ __forceinline__ void sum_pairs_strided_d(const float* __restrict__ p, size_t stride, int n, double& s1, double& s2) {
+  s1 = 0.0; s2 = 0.0;
+  int q = 0;
+  for (; q + 8 <= n; q += 8) {
+    f32x2 t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = *(const f32x2*)(p + (size_t)(q + e) * stride);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1 += (double)t[e][0]; s2 += (double)t[e][1]; }
+  }
+  if (q < n) {
+    f32x2 t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = *(const f32x2*)(p + (size_t)(q + (q + e < n ? e : 0)) * stride);  // clamped: always a valid address
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (q + e < n) { s1 += (double)t[e][0]; s2 += (double)t[e][1]; }
+  }
+}
+static __device__ __forceinline__ double shfl_xor_d(double v, int o) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, o); hi = __shfl_xor(hi, o);
+  return __hiloint2double(hi, lo);
+}
+// (mean, rstd) of a group from its fp64 totals
+static __device__ __forceinline__ void gn_mean_rstd(double s, double q, float inv_count, float eps, float& mean, float& rstd) {
+  // the element count is an integer below 2^24: recovered exactly from its fp32 reciprocal.  (Multiplying by the ROUNDED reciprocal scales
+  // E[x^2] and mean^2 by (1 + 6e-8) and (1 + 6e-8)^2: the difference is off by 6e-8 E[x^2] -- 0.5 % of the variance at |mean| = 300 sigma,
+  // which is what the first fp64 version of this function still showed: 1e-2 in the normalised output.)
+  const double n = rint(1.0 / (double)inv_count);
+  const double m = s / n;
+  const double var = q / n - m * m;
+  mean = (float)m;
+  rstd = rsqrtf(fmaxf((float)var, 0.f) + eps);
+}
+
 #define DTP_WAVE 64
 
 #define HIP_CHECK(x)                                                                        \
@@ -296,6 +336,28 @@ int dtp_xattn_tiles_per_wg(int S, int C, int N);
 bool dtp_xattn_supported(const XattnParams& p);
 int dtp_launch_xattn(const XattnParams& p, hipStream_t s);
 void dtp_xattn_init();
+
+// ---------------------------------------------------------------- register-chained out-projection + cross-attention (xchain.hip)
+// Y3 = softmax_16(LN(Y2) W1^T + b1) W2^T + b2 + Y2 with Y2 = A Wo^T + bo + Y, per sample; C = 320, S % 128 == 0; Y2 stays in registers
+struct XchainParams {
+  const f16* A; int lda;             // self-attention output, rows smp * S + m
+  const f16* Wo; int ldwo;           // attn1.to_out.0 weights, packed [C][ldwo] (pack_linear)
+  const float* bo;                   // [C] or null
+  const f16* Y; int ldy;             // residual of the projection (the block's proj_in output)
+  const f16* W1; long long w1_bs;    // per sample [128][C] (LayerNorm-2 gamma folded in)
+  const float *b1, *lns1;            // per sample [128]
+  const f16* W2; long long w2_bs;    // per sample [roundup(C, 128)][128]
+  const float* b2;                   // [C] or null
+  f16* Y3; int ldy3;
+  float* st_out;                     // [N * S][2] per-row (sum, sumsq) of the stored rows (ONE partial per row), or null
+  int S, C, N, sm_valid;
+  float ln_eps;
+  int dup;                           // de-duplicated UNet prefix (unet.hip Dup): A and Y hold samples [dup, N) only and samples [0, dup) read the
+                                     // rows of sample + dup (identical inputs up to here); 0 = A and Y hold all N samples
+};
+bool dtp_xchain_supported(const XchainParams& p);
+int dtp_launch_xchain(const XchainParams& p, hipStream_t s);
+void dtp_xchain_init();
 
 // ---------------------------------------------------------------- elementwise / layout (elementwise.hip)
 int dtp_launch_concat_channels(const f16* a, int lda, int Ca, const f16* b, int ldb, int Cb, f16* y, int ldy, long long rows,

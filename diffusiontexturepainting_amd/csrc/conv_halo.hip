@@ -190,17 +190,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
     const int groups = p.Cin / p.gn_cpg;
     {
       const int g = tid >> 3, j = tid & 7;
-      float s = 0.f, q = 0.f;
+      double s = 0.0, q = 0.0;  // (fp64 totals and variance: common.h sum_pairs_strided_d)
       if (g < groups)
-        sum_pairs_strided(p.gn_part + ((size_t)img * p.gn_nchunk + j) * groups * 2 + g * 2, (size_t)8 * groups * 2, (p.gn_nchunk - j + 7) / 8, s, q);
+        sum_pairs_strided_d(p.gn_part + ((size_t)img * p.gn_nchunk + j) * groups * 2 + g * 2, (size_t)8 * groups * 2, (p.gn_nchunk - j + 7) / 8, s, q);
 #pragma unroll
-      for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-      if (g < groups && j == 0) {
-        const float inv = 1.0f / ((float)(H * W) * (float)p.gn_cpg);
-        const float mean = s * inv;
-        gst[2 * g] = mean;
-        gst[2 * g + 1] = rsqrtf(fmaxf(q * inv - mean * mean, 0.f) + p.gn_eps);
-      }
+      for (int o = 4; o > 0; o >>= 1) { s += shfl_xor_d(s, o); q += shfl_xor_d(q, o); }
+      if (g < groups && j == 0) gn_mean_rstd(s, q, 1.0f / ((float)(H * W) * (float)p.gn_cpg), p.gn_eps, gst[2 * g], gst[2 * g + 1]);
     }
     __syncthreads();
     for (int c = tid; c < p.Cin; c += 256) {

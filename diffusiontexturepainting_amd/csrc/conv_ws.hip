@@ -55,7 +55,7 @@ struct WsGeom {
   static constexpr int CBLK = 1152;                     // pitch of a 1 KB (wave, tile, register group) block of the combine area
   static constexpr int CMB = 4 * (CO ? 1 : NT) * TM * 4 * CBLK;  // the four waves' partial tiles (fp32) of one combine round
   static constexpr int MAINB = (3 * PBYTES > CMB ? 3 * PBYTES : CMB);   // patches, later the combine area
-  static constexpr int STATB = (NI == 1 && NT == 2) ? (4 * NT * 32 * 2 + NT * 32 * 2) * 4 : 0;  // GF_GNSTATS: per-wave and per-workgroup channel sums
+  static constexpr int STATB = (NI == 1 && NT == 2) ? (4 * NT * 32 * 2 + NT * 32 * 2) * 8 : 0;  // GF_GNSTATS: per-wave and per-workgroup channel sums (fp64)
   static constexpr int LDS = MAINB + STATB;
   static constexpr int LT = (HL - 1) / (NT * TM);       // the tap in which the last patch piece of a channel block is issued
   static constexpr int WAITB = (17 - LT) * NT;          // vmcnt at the per-block barrier (see the main loop)
@@ -415,7 +415,9 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
   // here -- per (pixel tile, group) sums of the ROUNDED fp16 outputs -- instead of from a pass of its own over the tensor.
   constexpr bool CAN_STATS = G::STATB > 0;
   const bool stats = CAN_STATS && (p.flags & GF_GNSTATS) && p.splits == 1;
-  float* const sred = (float*)(smem + G::MAINB);     // [wave][NT * 32 channels][2], then [NT * 32][2] totals
+  // (round 6: fp64 from the lane butterflies on -- a chunk's partial is the sum of 128 x cpg squares; as a tree of fp32 sums its rounding
+  // decided the variance of a group whose mean is hundreds of standard deviations away from zero; one rounding to fp32 at the very end)
+  double* const sred = (double*)(smem + G::MAINB);   // [wave][NT * 32 channels][2], then [NT * 32][2] totals
 #pragma unroll
   for (int i0 = 0; i0 < NT; i0 += RT) {
     if (i0 > 0) __syncthreads();  // the previous round's reads are done
@@ -470,15 +472,17 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
       }
       if constexpr (CAN_STATS) {
         if (stats) {  // this wave's 8 pixels (lanes 8 apart share a channel quad): fixed-order butterfly, then one writer per quad
+          double sd[4], qd[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
+            sd[e] = (double)ssum[e]; qd[e] = (double)qsum[e];
 #pragma unroll
-            for (int o = 8; o < 64; o <<= 1) { ssum[e] += __shfl_xor(ssum[e], o); qsum[e] += __shfl_xor(qsum[e], o); }
+            for (int o = 8; o < 64; o <<= 1) { sd[e] += shfl_xor_d(sd[e], o); qd[e] += shfl_xor_d(qd[e], o); }
           }
           if (lane < 8) {
-            float* d = sred + ((wave * NT + i0 + i) * 32 + 4 * c4) * 2;
+            double* d = sred + ((wave * NT + i0 + i) * 32 + 4 * c4) * 2;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { d[2 * e] = ssum[e]; d[2 * e + 1] = qsum[e]; }
+            for (int e = 0; e < 4; ++e) { d[2 * e] = sd[e]; d[2 * e + 1] = qd[e]; }
           }
         }
       }
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
   if constexpr (CAN_STATS) {
     if (stats) {
       __syncthreads();
-      float* const tot = sred + 4 * NT * 32 * 2;
+      double* const tot = sred + 4 * NT * 32 * 2;
       if (tid < NT * 32 * 2) tot[tid] = ((sred[tid] + sred[NT * 64 + tid]) + sred[2 * NT * 64 + tid]) + sred[3 * NT * 64 + tid];
       __syncthreads();
       // partial sums [image][2 * pixel tiles][groups][2]: chunk 2 * tile + (n-range & 1).  A group overlaps one n-range (64 channels >=
@@ -499,12 +503,12 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
       const int g = g_lo + tid;
       if (g <= g_hi) {
         const int a = max(g * cpg, c_lo), b = min((g + 1) * cpg, c_hi);
-        float sg = 0.f, qg = 0.f;
+        double sg = 0.0, qg = 0.0;
         for (int c = a; c < b; ++c) { sg += tot[(c - c_lo) * 2]; qg += tot[(c - c_lo) * 2 + 1]; }
         const int ntile = tiles_x * tiles_y, pt = ty * tiles_x + tx;
         float* const base = p.st_out + ((size_t)img0 * 2 * ntile + 2 * pt) * groups * 2;
         float* const mine = base + (size_t)(nr & 1) * groups * 2 + g * 2;
-        mine[0] = sg; mine[1] = qg;
+        mine[0] = (float)sg; mine[1] = (float)qg;
         if (g * cpg >= c_lo && (g + 1) * cpg <= c_hi) {
           float* const other = base + (size_t)((nr & 1) ^ 1) * groups * 2 + g * 2;
           other[0] = 0.f; other[1] = 0.f;

@@ -363,6 +363,15 @@ T Builder::alloc(int B, int H, int W, int C) {
 }
 void Builder::release(const T& t) { ctx_pool_put(c, t.p); }
 
+// Column ranges of an lnlin_kernel launch when no tuner picks them: the LARGEST count the kernel accepts within one partial per 64
+// output columns -- independent of the row count, so that the row-statistics partials (one per range) are summed in the same grouping
+// whatever the batch (the de-duplicated UNet prefix evaluates two of three samples and must stay bit-identical with the tuner off).
+static int lnlin_default_ranges(const GemmParams& p) {
+  for (int r = (p.N + 63) / 64; r >= 1; --r)
+    if (dtp_lnlin_supported(p, r)) return r;
+  return 0;
+}
+
 // Which conv outputs can carry their consumer GroupNorm's statistics (GF_GNSTATS of the two-n-tile convws builds)?  ONE predicate for
 // Builder::claim_stats (which re-pushes the conv with the flag) and for tune_gemm (which credits such a candidate with the statistics
 // pass it saves) -- round-5 advisor: the two had repeated parts of each other's conditions (chunk cap, channels-per-group range) and
@@ -530,6 +539,54 @@ int Builder::gn_linear(const T& x, const NormW& n, float eps, const ConvW& w, T&
   const bool from_epilogue = !claimed && claim_stats(x, &ep_part, &ep_chunks);
   const size_t slab_bytes = claimed ? ((dtp_gemm_workspace_bytes(gp) + 255) & ~(size_t)255) : 0;
   cc->ws_need = std::max(cc->ws_need, slab_bytes + dtp_groupnorm_ws_bytes(N, HW, C, 32));
+  // Round 6: where the activation-stationary Linear takes the problem (K = C in {320, 640}: UNet levels 0-1), the GroupNorm is applied to
+  // its RESIDENT activation fragments (lnlin_kernel GNA) -- [statistics ->] ONE launch on the raw tensor with the shared weights; the fold
+  // launch (190 per batch-1 stamp), the per-sample weight copies and the grouped problem disappear.  $DTP_NO_GNA_LNLIN=1: the fold (A/B).
+  static const bool gna_off = [] { const char* e = getenv("DTP_NO_GNA_LNLIN"); return e && e[0] && e[0] != '0'; }();
+  if (!gna_off && (C == 320 || C == 640) && (HW & 127) == 0 && !fp8) {
+    GemmParams g = {};
+    g.A = x.p; g.lda = x.ld; g.W = w.w; g.ldw = w.ldw; g.nkb = w.ldw / 64;
+    g.M = HW; g.N = w.cout; g.K = w.K;
+    g.bias = w.b; g.flags = (w.b ? GF_BIAS : 0) | GF_GNAPPLY;
+    g.batch = N; g.a_bs = (long long)HW * x.ld; g.c_bs = (long long)HW * w.cout; g.w_bs = 0; g.bias_bs = 0;
+    g.gn_gamma = n.g; g.gn_beta = n.b; g.gn_eps = eps; g.gn_cpg = C / 32;
+    g.gn_nchunk = from_epilogue ? ep_chunks : dtp_groupnorm_stat_chunks(HW);
+    g.gn_part = (const float*)x.p;  // (a non-null placeholder for the support check: the partials block is planned below)
+    g.ldc = w.cout;
+    if (lnlin_default_ranges(g) > 0) {
+      // the partial sums outlive the statistics launch inside the shared workspace only until the next split launch: own planned buffer
+      float* part = ep_part;
+      if (!from_epilogue) {
+        std::vector<MemRange> busy;
+        if (claimed && (gp.flags & GF_RESID)) busy.push_back({gp.R, (size_t)gp.M * gp.ldr * sizeof(f16)});
+        part = (float*)pool_get_clear_of(cc, dtp_groupnorm_ws_bytes(N, HW, C, 32), busy);
+        if (!part) { dtp_set_error("gn_linear: no partials block"); return DTP_ERR_HIP; }
+        const T xx = x;
+        const bool has_bias = claimed && (gp.flags & GF_BIAS) != 0;
+        push(PK_GN, 0.0, 2.0 * (double)xx.rows() * C, [=](hipStream_t s, int step) {
+          if (claimed) {
+            GnReduceSrc rd;
+            rd.part = cc->ws; rd.splits = gp.splits; rd.slab = (long long)gp.M * gp.N; rd.ldp = gp.N;
+            rd.bias = !has_bias ? nullptr : (bso >= 0 ? cc->temb_table + (size_t)step * cc->unet.temb_total + bso : gp.bias);
+            rd.R = (gp.flags & GF_RESID) ? gp.R : nullptr; rd.ldr = gp.ldr;
+            return dtp_launch_groupnorm_stats(xx.p, xx.ld, part, N, HW, C, 32, &rd, s);
+          }
+          return dtp_launch_groupnorm_stats(xx.p, xx.ld, part, N, HW, C, 32, nullptr, s);
+        }, std::string(claimed ? "reduce+gn-stats" : "gn-stats") + " B=" + std::to_string(N) + " HW=" + std::to_string(HW) + " C=" + std::to_string(C) + " (apply in proj_in)");
+      }
+      g.gn_part = part;
+      y = alloc(x.B, x.H, x.W, w.cout);
+      if (!y.p) return DTP_ERR_HIP;
+      g.C = y.p; g.ldc = y.ld; g.c_bs = (long long)HW * y.ld;
+      if (emit && emit->buf) {
+        g.flags |= GF_ROWSTATS; g.st_out = emit->buf; g.st_rows = N * HW;
+        if (emit->rows_total > 0) { g.st_out = emit->buf + (size_t)emit->row_off * 2; g.st_rows = emit->rows_total; }
+      }
+      RC(push_gemm(cc, prog, g, -1, (double)w.K, (emit && emit->buf) ? emit : nullptr));
+      ctx_pool_put(cc, part);
+      return DTP_OK;
+    }
+  }
   void *pw = nullptr, *pb = nullptr;
   RC(ctx_pool_get(cc, (size_t)N * Cp * w.ldw * sizeof(f16), &pw));
   RC(ctx_pool_get(cc, (size_t)N * Cp * sizeof(float), &pb));
@@ -949,7 +1006,13 @@ int push_gemm(Ctx* c, Prog* prog, GemmParams p, int bias_step_off, double k_alg,
     p.splits = 1; p.kb_per_split = p.nkb;
     tile = 24 + ((p.flags & GF_GEGLU) ? (p.M >= 512 ? 0 : 3) : (p.M >= 512 ? 0 : 2));
   }
-  if (p.flags & GF_GNAPPLY) { tile = (p.Hi * p.Wi <= 256) ? 14 : 12; p.splits = 1; p.kb_per_split = p.nkb; }  // halo kernel only
+  if ((p.flags & GF_GNAPPLY) && (p.flags & GF_CONV3)) { tile = (p.Hi * p.Wi <= 256) ? 14 : 12; p.splits = 1; p.kb_per_split = p.nkb; }  // halo kernel only
+  if ((p.flags & GF_GNAPPLY) && !(p.flags & GF_CONV3)) {  // dense: GroupNorm on the resident fragments of lnlin_kernel, nothing else applies it
+    tile = DTP_TILE_LNLIN; p.splits = 1; p.kb_per_split = p.nkb;
+    const int pick = lnlin_default_ranges(p);
+    if (!pick) { dtp_set_error("push_gemm: no lnlin configuration for the GroupNorm-on-load Linear (M %d N %d K %d)", p.M, p.N, p.K); return DTP_ERR_ARG; }
+    p.col_ranges = pick;
+  }
   if (c->autotune) RC(tune_gemm(c, p, &tile));
   if (emit) {  // the consumer must know how many partials this launch configuration writes per row
     int bm = 0, bn = 128, ns = 0;

@@ -42,9 +42,17 @@ constexpr int LNLIN_LDS = 3 * UNIT_BYTES + 4 * STG_BYTES + VEC_BYTES;
 // statistics the next LayerNorm-folded GEMM wants: GF_ROWSTATS, one partial per column range) and proj_in as a grouped problem
 // (p.batch samples of M rows, per-sample weights / biases: the GroupNorm folded into them).  The residual is added and the
 // statistics are taken in the transposed store phase, where a lane holds 16 bytes of one output row.
-template <int KU, bool GEGLU, bool LN = true>
+// GNA (round 6, plain variant only): A is the RAW input of a GroupNorm WITHOUT activation whose output this Linear consumes (the
+// transformer's norm -> proj_in, models.py Transformer2DModel): the normalisation y = x a_b[c] + d_b[c] (a = gamma rstd, d = beta -
+// mean a per sample b and channel c) is applied to the RESIDENT activation fragments, once per workgroup, while they sit in registers
+// -- no apply pass over the tensor, no per-sample folded weights (gn_fold_weights_kernel: 190 launches per batch-1 stamp), the
+// shared weight matrix as is.  The workgroup builds its sample's (a, d) table from the statistics partials gn_part
+// [sample][gn_nchunk][32][2] (fp64 totals) under the latency of its activation DMA; the arithmetic per element is gn_apply_kernel's
+// (fp32 fma, one rounding to fp16): bit-identical to GroupNorm-apply followed by the plain kernel.
+template <int KU, bool GEGLU, bool LN = true, bool GNA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void lnlin_kernel(const GemmParams p) {  // two workgroups per CU: <= 256 registers
   static_assert(LN || !GEGLU, "the plain variant has no GEGLU epilogue");
+  static_assert(!GNA || (!LN && !GEGLU), "GroupNorm-on-load exists for the plain variant");
   constexpr int K = KU * 320, NKB = K / 64, KST = K / 16;  // k-blocks, k-steps of the whole contraction
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;
@@ -64,7 +72,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
   const int rb = (b & 7) + 8 * (b / (8 * nsplit));
   if (rb >= rblocks) return;
   const int m0 = rb * 128;
-  const int smp = p.batch > 1 ? m0 / p.M : 0;  // sample of this row block
+  const int smp_rows = p.batch > 1 ? m0 / p.M : 0;  // sample of this row block
+  const int smp = GNA ? 0 : smp_rows;              // (GNA: one weight matrix / bias for every sample)
   const int nchunks_all = GEGLU ? (p.N >> 6) : (p.N >> 5);  // 32-column output chunks
   const int cper = (nchunks_all + nsplit - 1) / nsplit;
   const int c0 = split * cper, c1 = min(c0 + cper, nchunks_all);
@@ -95,6 +104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
   // five k-blocks of C = 320 were five dependent memory round trips (~4 us per launch); fragment-shaped loads straight into the
   // registers (one round trip) measured slower still: 32-byte row segments.  Every wave then reads the fragments of ITS 32 rows.
   static_assert(4 * 16384 <= 3 * UNIT_BYTES + 4 * STG_BYTES, "activation staging must not reach the vector table");
+  static_assert(!GNA || 4 * 16384 + (64 + 2 * K) * 4 <= 3 * UNIT_BYTES + 4 * STG_BYTES, "the GroupNorm table fits between the staging area and the vector table");
   f16x8 af[KST];
   {
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, OOB, 0x00020000);
@@ -113,8 +123,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + (i * 32 + wave * 8) * 128), 16, vo, kb * 128, 0, 0);
       }
     };
+    // GNA: this thread's statistics partials are requested BEFORE the activation DMA (their wait then does not drain the DMA queue)
+    [[maybe_unused]] double gs = 0.0, gq = 0.0;
+    [[maybe_unused]] float ggm[3] = {0.f, 0.f, 0.f}, gbt[3] = {0.f, 0.f, 0.f};  // gamma / beta of channels tid, tid + 256, tid + 512 (K <= 640)
+    if constexpr (GNA) {
+#pragma unroll
+      for (int k = 0; k < (K + 255) / 256; ++k) {
+        const int c = min(tid + k * 256, K - 1);
+        ggm[k] = p.gn_gamma[c]; gbt[k] = p.gn_beta[c];
+      }
+      const int g = tid >> 3, j = tid & 7;  // 32 groups x 8 lanes
+      sum_pairs_strided_d(p.gn_part + ((size_t)smp_rows * p.gn_nchunk + j) * 64 + g * 2, (size_t)8 * 64, (p.gn_nchunk - j + 7) / 8, gs, gq);
+    }
 #pragma unroll
     for (int kb = 0; kb < 4 && kb < NKB; ++kb) issue_a(kb);
+    if constexpr (GNA) {
+      // (a, d) of the sample's K channels -> LDS behind the activation staging area (bytes 65536 .. of the ring + staging region, which
+      // phase 1 does not touch); published by the k-block barriers below, read once after the loop
+      float* const gst = (float*)(smem + 4 * 16384);          // [32][2] mean, rstd
+      float* const gtab = gst + 64;                           // [K] a, then [K] d
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) { gs += shfl_xor_d(gs, o); gq += shfl_xor_d(gq, o); }
+      if ((tid & 7) == 0) gn_mean_rstd(gs, gq, 1.0f / ((float)p.M * (float)p.gn_cpg), p.gn_eps, gst[2 * (tid >> 3)], gst[2 * (tid >> 3) + 1]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int k = 0; k < (K + 255) / 256; ++k) {
+        const int c = tid + k * 256;
+        if (c < K) {
+          const int g = c / p.gn_cpg;
+          const float a = gst[2 * g + 1] * ggm[k];
+          gtab[c] = a;
+          gtab[K + c] = fmaf(-gst[2 * g], a, gbt[k]);  // (gn_apply_kernel's bo = fma(-mean, a, beta))
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the table is in LDS before this wave's next barrier
+    }
     const int row = wave * 32 + mrow;
     const int akey = (row >> 1) & 7;
 #pragma unroll
@@ -131,6 +175,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         af[kb * 4 + ks] = *(const f16x8*)(smem + (kb & 3) * 16384 + row * 128 + ((((ks * 2 + half) ^ akey)) << 4));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragments are in registers before anyone overwrites the slot
       (void)dummy;
+    }
+  }
+  if constexpr (GNA) {  // normalise the resident fragments: fragment i of this lane = channels 16 i + 8 half .. + 7 of its row
+    const float* const gtab = (const float*)(smem + 4 * 16384) + 64;
+#pragma unroll
+    for (int i = 0; i < KST; ++i) {
+      // (two fragments per scheduling region: left alone, hipcc hoists the table reads of all 20 / 40 fragments -- 16 registers each -- above
+      // the arithmetic and the K = 640 build spilled 153 registers)
+      if ((i & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+      const int c0 = 16 * i + 8 * half;
+      const f32x4 a0 = *(const f32x4*)(gtab + c0), a1 = *(const f32x4*)(gtab + c0 + 4);
+      const f32x4 d0 = *(const f32x4*)(gtab + K + c0), d1 = *(const f32x4*)(gtab + K + c0 + 4);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = fmaf((float)af[i][e], e < 4 ? a0[e] : a1[e - 4], e < 4 ? d0[e] : d1[e - 4]);
+        asm volatile("" : "+v"(f));  // two roundings (fp32, then fp16) as in gn_apply_kernel: no v_fma_mixlo_f16
+        o[e] = (f16)f;
+      }
+      asm volatile("" : "+v"(o));  // the fragment is PACKED again here (four registers): updated element by element in place, the halves
+      af[i] = o;                   // stayed in eight registers each up to their MFMA -- 160 / 320 registers of fragments, 153 spilled at K = 640
     }
   }
   // LayerNorm statistics of this lane's row from the resident fragments (each half-wave holds alternate 8-element chunks)
@@ -336,11 +401,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
   }
 }
 
-template <int KU, bool GEGLU, bool LN = true>
+template <int KU, bool GEGLU, bool LN = true, bool GNA = false>
 int launch(const GemmParams& p, hipStream_t s) {
   const int rblocks = (p.M * (p.batch > 1 ? p.batch : 1) + 127) >> 7;
   const int blocks = ((rblocks + 7) / 8) * 8 * p.splits;
-  hipLaunchKernelGGL((lnlin_kernel<KU, GEGLU, LN>), dim3(blocks), dim3(256), LNLIN_LDS, s, p);
+  hipLaunchKernelGGL((lnlin_kernel<KU, GEGLU, LN, GNA>), dim3(blocks), dim3(256), LNLIN_LDS, s, p);
   return hipGetLastError() == hipSuccess ? DTP_OK : DTP_ERR_HIP;
 }
 
@@ -353,6 +418,8 @@ void dtp_lnlin_init() {
   (void)hipFuncSetAttribute((const void*)lnlin_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
   (void)hipFuncSetAttribute((const void*)lnlin_kernel<1, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
   (void)hipFuncSetAttribute((const void*)lnlin_kernel<2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
+  (void)hipFuncSetAttribute((const void*)lnlin_kernel<1, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
+  (void)hipFuncSetAttribute((const void*)lnlin_kernel<2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LNLIN_LDS);
 }
 
 // diagnostic (tools/scratch, not in include/dtp.h): workgroups of one instantiation the runtime will keep resident per CU
@@ -371,8 +438,13 @@ extern "C" int dtp_debug_lnlin_occupancy(int ku, int geglu, int ln) {
 // by the global row).  nsplit (1..): column ranges per 128-row block, at most MAX_CHUNKS chunks each.
 bool dtp_lnlin_supported(const GemmParams& p, int nsplit) {
   const bool ln = (p.flags & GF_LNFOLD) != 0;
-  const int allowed = ln ? (GF_LNFOLD | GF_BIAS | GF_GEGLU | GF_MFAST) : (GF_BIAS | GF_RESID | GF_ROWSTATS | GF_MFAST);
+  const int allowed = ln ? (GF_LNFOLD | GF_BIAS | GF_GEGLU | GF_MFAST) : (GF_BIAS | GF_RESID | GF_ROWSTATS | GF_MFAST | GF_GNAPPLY);
   if ((p.flags & ~allowed) || p.W8 || p.A2 || (ln && (!p.lns || p.batch > 1))) return false;
+  if (p.flags & GF_GNAPPLY) {  // GroupNorm (32 groups, no activation) of the input applied on the resident fragments: a grouped problem of
+    // p.batch >= 1 samples with M % 128 == 0 rows each that share ONE weight matrix (w_bs = bias_bs = 0), dense operands (no conv mode)
+    if ((p.flags & GF_CONV3) || !p.gn_part || !p.gn_gamma || !p.gn_beta || p.gn_nchunk < 1 || p.gn_silu || p.gn_cpg < 1 || p.K != 32 * p.gn_cpg) return false;
+    if ((p.M & 127) || p.w_bs != 0 || p.bias_bs != 0) return false;
+  }
   if (p.K != 320 && p.K != 640) return false;
   if ((p.lda & 7) || (p.ldw & 7) || (p.ldc & 7) || p.ldw < p.K) return false;
   const bool geglu = (p.flags & GF_GEGLU) != 0;
@@ -399,7 +471,8 @@ int dtp_launch_lnlin(const GemmParams& pin, int nsplit, hipStream_t s) {
   p.splits = nsplit;
   const bool geglu = (p.flags & GF_GEGLU) != 0, ln = (p.flags & GF_LNFOLD) != 0;
   int rc;
-  if (!ln) rc = p.K == 320 ? launch<1, false, false>(p, s) : launch<2, false, false>(p, s);
+  if (!ln && (p.flags & GF_GNAPPLY)) rc = p.K == 320 ? launch<1, false, false, true>(p, s) : launch<2, false, false, true>(p, s);
+  else if (!ln) rc = p.K == 320 ? launch<1, false, false>(p, s) : launch<2, false, false>(p, s);
   else if (p.K == 320) rc = geglu ? launch<1, true>(p, s) : launch<1, false>(p, s);
   else rc = geglu ? launch<2, true>(p, s) : launch<2, false>(p, s);
   if (rc != DTP_OK) dtp_set_error("lnlin launch failed: %s", hipGetErrorString(hipGetLastError()));

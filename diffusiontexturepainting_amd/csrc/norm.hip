@@ -12,6 +12,11 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += shfl_xor_d(v, o);
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -111,17 +116,19 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int ldx, float* __res
   __syncthreads();
   float* out = partial + ((size_t)b * nchunk + chunk) * groups * 2;
   for (int g = threadIdx.x; g < groups; g += blockDim.x) {
-    float s = 0.f, q = 0.f;
+    // (round 6) the threads' sums -- a few pixels each: exact products, fp32 sums of <= 40 terms -- are added in fp64 and the chunk's
+    // partial is rounded to fp32 ONCE: its error is one ulp of itself, not the accumulated rounding of a 50-term fp32 chain
+    double s = 0.0, q = 0.0;
     const int cfirst = (g * cpg) >> 3, clast = ((g + 1) * cpg - 1) >> 3;
     for (int c = cfirst; c <= clast; ++c) {
       const int sel = ((c * 8) / cpg == g) ? 0 : 2;  // this chunk's first or second group
       for (int r = 0; r < rows; ++r) {
-        s += part[(r * nch + c) * 4 + sel];
-        q += part[(r * nch + c) * 4 + sel + 1];
+        s += (double)part[(r * nch + c) * 4 + sel];
+        q += (double)part[(r * nch + c) * 4 + sel + 1];
       }
     }
-    out[g * 2] = s;
-    out[g * 2 + 1] = q;
+    out[g * 2] = (float)s;
+    out[g * 2 + 1] = (float)q;
   }
 }
 
@@ -183,17 +190,17 @@ __global__ void gn_stats_reduce_kernel(const float* __restrict__ part, int split
   const int gfirst = cbase / cpg, gcount = cs_ch / cpg;
   for (int gi = threadIdx.x; gi < gcount; gi += blockDim.x) {
     const int g = gfirst + gi;
-    float s = 0.f, q = 0.f;
+    double s = 0.0, q = 0.0;  // (fp64 combine, one rounding per partial: see gn_stats_kernel)
     const int cfirst = (g * cpg - cbase) >> 3, clast = ((g + 1) * cpg - 1 - cbase) >> 3;
     for (int c = cfirst; c <= clast; ++c) {
       const int sel = ((cbase + c * 8) / cpg == g) ? 0 : 2;
       for (int r = 0; r < rows; ++r) {
-        s += red[(r * nch + c) * 4 + sel];
-        q += red[(r * nch + c) * 4 + sel + 1];
+        s += (double)red[(r * nch + c) * 4 + sel];
+        q += (double)red[(r * nch + c) * 4 + sel + 1];
       }
     }
-    out[g * 2] = s;
-    out[g * 2 + 1] = q;
+    out[g * 2] = (float)s;
+    out[g * 2 + 1] = (float)q;
   }
 }
 
@@ -223,17 +230,12 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const f16* __restrict__ 
   }
   {
     const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
-    float s = 0.f, q = 0.f;
-    if (g < groups)  // chunks j, j + 8, ... in order, loads up front (common.h)
-      sum_pairs_strided(partial + ((size_t)b * nchunk + j) * groups * 2 + g * 2, (size_t)8 * groups * 2, (nchunk - j + 7) / 8, s, q);
+    double s = 0.0, q = 0.0;
+    if (g < groups)  // chunks j, j + 8, ... in order, loads up front; fp64 totals and variance (common.h: sum_pairs_strided_d)
+      sum_pairs_strided_d(partial + ((size_t)b * nchunk + j) * groups * 2 + g * 2, (size_t)8 * groups * 2, (nchunk - j + 7) / 8, s, q);
 #pragma unroll
-    for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-    if (g < groups && j == 0) {
-      const float mean = s * inv_count;
-      const float var = fmaxf(q * inv_count - mean * mean, 0.f);
-      st[g * 2] = mean;
-      st[g * 2 + 1] = rsqrtf(var + eps);
-    }
+    for (int o = 4; o > 0; o >>= 1) { s += shfl_xor_d(s, o); q += shfl_xor_d(q, o); }
+    if (g < groups && j == 0) gn_mean_rstd(s, q, inv_count, eps, st[g * 2], st[g * 2 + 1]);
     if (groups > 32) {  // second half of the groups (not used on this path, kept for generality)
       const int g2 = g + 32;
       float s2 = 0.f, q2 = 0.f;
@@ -330,7 +332,7 @@ template <int G>
 __global__ __launch_bounds__(1024) void gn_fused_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int HW,
                                                         int cpg, int silu, float inv_count, float eps) {
-  __shared__ float red[16][2 * G];
+  __shared__ double red[16][2 * G];
   __shared__ float st[2 * G];
   const int nthr = blockDim.x, nwave = blockDim.x >> 6;
   const int b = blockIdx.y, slab = blockIdx.x;
@@ -358,23 +360,19 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const f16* __restrict__ 
       if (g == g0 + 1) { s[g] += a1; q[g] += b1; }
     }
   }
+  // (round 6) a thread's sums cover a few 8-element items: fp32 is exact enough there; everything above -- the wave butterflies, the
+  // sum over the waves, E[x^2] - mean^2 -- runs in fp64 (large group means: test_groupnorm_large_group_means)
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    s[g] = wave_sum(s[g]);
-    q[g] = wave_sum(q[g]);
-  }
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int g = 0; g < G; ++g) { red[threadIdx.x >> 6][2 * g] = s[g]; red[threadIdx.x >> 6][2 * g + 1] = q[g]; }
+    const double sd = wave_sum_d((double)s[g]), qd = wave_sum_d((double)q[g]);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][2 * g] = sd; red[threadIdx.x >> 6][2 * g + 1] = qd; }
   }
   __syncthreads();
   if (threadIdx.x < G) {
     const int g = threadIdx.x;
-    float ss = 0.f, qq = 0.f;
+    double ss = 0.0, qq = 0.0;
     for (int w = 0; w < nwave; ++w) { ss += red[w][2 * g]; qq += red[w][2 * g + 1]; }
-    const float mean = ss * inv_count;
-    st[2 * g] = mean;
-    st[2 * g + 1] = rsqrtf(fmaxf(qq * inv_count - mean * mean, 0.f) + eps);
+    gn_mean_rstd(ss, qq, inv_count, eps, st[2 * g], st[2 * g + 1]);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < total; i += nthr) {
@@ -412,7 +410,7 @@ __global__ __launch_bounds__(1024) void gn_reduce_fused_kernel(const float* __re
                                                                int cpg, int silu, float inv_count, float eps, int Cx) {
   // Cx: channels [0, Cx) come from the slabs (and are written to c_out); channels >= Cx are already in c_out -- the other half of a
   // zero-copy concatenation whose first half the split conv produced (round 5: its reduce used to be a launch of its own)
-  __shared__ float red[16][2 * G];
+  __shared__ double red[16][2 * G];
   __shared__ float st[2 * G];
   const int nthr = blockDim.x, nwave = blockDim.x >> 6;
   const int b = blockIdx.y, sl = blockIdx.x;
@@ -474,19 +472,16 @@ __global__ __launch_bounds__(1024) void gn_reduce_fused_kernel(const float* __re
     }
   }
 #pragma unroll
-  for (int g = 0; g < G; ++g) { s[g] = wave_sum(s[g]); q[g] = wave_sum(q[g]); }
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int g = 0; g < G; ++g) { red[threadIdx.x >> 6][2 * g] = s[g]; red[threadIdx.x >> 6][2 * g + 1] = q[g]; }
+  for (int g = 0; g < G; ++g) {  // fp64 from the wave butterflies on (see gn_fused_kernel)
+    const double sd = wave_sum_d((double)s[g]), qd = wave_sum_d((double)q[g]);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][2 * g] = sd; red[threadIdx.x >> 6][2 * g + 1] = qd; }
   }
   __syncthreads();
   if (threadIdx.x < G) {
     const int g = threadIdx.x;
-    float ss = 0.f, qq = 0.f;
+    double ss = 0.0, qq = 0.0;
     for (int w = 0; w < nwave; ++w) { ss += red[w][2 * g]; qq += red[w][2 * g + 1]; }
-    const float mean = ss * inv_count;
-    st[2 * g] = mean;
-    st[2 * g + 1] = rsqrtf(fmaxf(qq * inv_count - mean * mean, 0.f) + eps);
+    gn_mean_rstd(ss, qq, inv_count, eps, st[2 * g], st[2 * g + 1]);
   }
   __syncthreads();
 #pragma unroll
@@ -557,16 +552,12 @@ __global__ __launch_bounds__(256) void gn_fold_weights_kernel(const f16* __restr
   }
   {
     const int g = tid >> 3, j = tid & 7;
-    float s = 0.f, q = 0.f;
-    if (g < groups)  // chunks j, j + 8, ... in order, loads up front (common.h)
-      sum_pairs_strided(partial + ((size_t)b * nchunk + j) * groups * 2 + g * 2, (size_t)8 * groups * 2, (nchunk - j + 7) / 8, s, q);
+    double s = 0.0, q = 0.0;
+    if (g < groups)  // chunks j, j + 8, ... in order, loads up front; fp64 totals and variance (common.h: sum_pairs_strided_d)
+      sum_pairs_strided_d(partial + ((size_t)b * nchunk + j) * groups * 2 + g * 2, (size_t)8 * groups * 2, (nchunk - j + 7) / 8, s, q);
 #pragma unroll
-    for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-    if (g < groups && j == 0) {
-      const float mean = s * inv_count;
-      st[g * 2] = mean;
-      st[g * 2 + 1] = rsqrtf(fmaxf(q * inv_count - mean * mean, 0.f) + eps);
-    }
+    for (int o = 4; o > 0; o >>= 1) { s += shfl_xor_d(s, o); q += shfl_xor_d(q, o); }
+    if (g < groups && j == 0) gn_mean_rstd(s, q, inv_count, eps, st[g * 2], st[g * 2 + 1]);
   }
   __syncthreads();
 #pragma unroll

@@ -212,7 +212,50 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
   a.B = x.B; a.H = x.H; a.W = x.W;
   RC(b.alloc_stats((long long)N * S, C, st2));
   T xin = x;  // the block input for all N samples (residual of the last GEMM)
-  if (dB > 0) {
+  bool chained = false;  // out1 + cross-attention done by xchain_kernel
+  {
+    // Round 6: at level 0 (C = 320) the output projection, its residual, LayerNorm-2 and the whole fused cross-attention run as ONE
+    // register-chained launch (xchain.hip): y2 and its row statistics never reach memory.  With a de-duplicated prefix the uncond samples
+    // read the cond samples' rows of a and y (the kernel's `dup`): their y2 is recomputed instead of copied.  The launch has one workgroup
+    // per 128 rows: it is used where that is at least ~a third of the CUs (512^2: 96 at batch 1; not the 24 of a 256^2 stamp, where the
+    // two well-parallelised launches it replaces are faster: +2 % per stamp measured).  ($DTP_NO_XCHAIN=1: the two launches, A/B.)
+    static const bool xc_off = [] { const char* e = getenv("DTP_NO_XCHAIN"); return e && e[0] && e[0] != '0'; }();
+    XchainParams xc = {};
+    const int i = w.kv_index;
+    xc.A = a.p; xc.lda = a.ld; xc.Wo = w.out1.w; xc.ldwo = w.out1.ldw; xc.bo = w.out1.b; xc.Y = y.p; xc.ldy = y.ld;
+    xc.W1 = up.xW1[i]; xc.w1_bs = (long long)128 * C; xc.b1 = up.xb1[i]; xc.lns1 = up.xl1[i];
+    xc.W2 = up.xW2[i]; xc.w2_bs = (long long)((C + 127) / 128 * 128) * 128; xc.b2 = w.out2.b;
+    xc.S = S; xc.C = C; xc.N = N; xc.sm_valid = 14; xc.ln_eps = 1e-5f; xc.dup = dB;
+    xc.Y3 = a.p; xc.ldy3 = C;  // (placeholder for the support check)
+    if (!xc_off && b.c->fuse_xattn && !b.fp8 && w.out1.K == C && w.out1.cout == C && !w.out1.lns && (long long)(S / 128) * N >= b.c->num_cu / 4 &&
+        dtp_xchain_supported(xc)) {
+      b.release_stats(st2);
+      RC(b.alloc_stats((long long)N * S, C, st3));
+      y3 = b.alloc(N, x.H, x.W, C);
+      if (!y3.p) return DTP_ERR_HIP;
+      xc.Y3 = y3.p; xc.ldy3 = y3.ld; xc.st_out = st3.buf;
+      st3.parts = 1; st3.M = N * S;
+      b.push(PK_XATTN, 2.0 * N * S * ((double)C * C + 2.0 * 128.0 * C), 2.0 * N * (3.0 * S * C + (double)C * C + 2.0 * 128 * C),
+             [=](hipStream_t s, int) { return dtp_launch_xchain(xc, s); }, "xchain M=" + std::to_string(S) + " C=" + std::to_string(C) + " x" + std::to_string(N));
+      chained = true;
+      if (dB > 0) {  // the other two tensors the branches share still get their uncond rows by ONE row-copy launch
+        CopySegs cs = {};
+        const long long rB = (long long)dB * S;
+        const T &sk = dup->skip_full, &xf = dup->x_full;
+        cs.src[0] = (const char*)(sk.p + rB * sk.ld); cs.dst[0] = (char*)sk.p; cs.rows[0] = rB; cs.row_bytes[0] = (long long)sk.C * 2;
+        cs.src_stride[0] = cs.dst_stride[0] = (long long)sk.ld * 2;
+        cs.src[1] = (const char*)(xf.p + rB * xf.ld); cs.dst[1] = (char*)xf.p; cs.rows[1] = rB; cs.row_bytes[1] = (long long)xf.C * 2;
+        cs.src_stride[1] = cs.dst_stride[1] = (long long)xf.ld * 2;
+        cs.n = 2;
+        double bytes = 0;
+        for (int k = 0; k < cs.n; ++k) bytes += 2.0 * cs.rows[k] * cs.row_bytes[k];
+        b.push(PK_ELEM, 0.0, bytes, [=](hipStream_t s, int) { return dtp_launch_copy_rows(cs, s); }, "dup uncond<-cond rows=" + std::to_string(rB));
+        xin = dup->x_full;
+      }
+    }
+  }
+  if (chained) {
+  } else if (dB > 0) {
     y2 = b.alloc(N, x.H, x.W, C);
     if (!y2.p) return DTP_ERR_HIP;
     const T y2s = samples(y2, dB, x.B);
@@ -240,6 +283,7 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
     RC(b.linear(a, w.out1, &y, 0, y2, &st2));
   }
   b.release(a); b.release(y);
+  if (!chained) {
   // Cross-attention over 14 context tokens: softmax_j(LN2(y2) Wq'^T K^T) V Wo^T collapses to two grouped GEMMs against
   // per-sample matrices prepared once per stamp (UNetProg::xW1 / xW2): scores + group softmax, then the value-output product.
   XattnParams xp = {};
@@ -301,6 +345,7 @@ static int transformer(Builder& b, const T& x, const XfW& w, const UNetProg& up,
     RC(push_gemm(b.c, b.prog, h, -1, 128.0, st3.buf ? &st3 : nullptr));
     b.release(pm); b.release(y2);
   }
+  }  // !chained
   RC(b.linear(y3, w.ff1, nullptr, GF_GEGLU, f, nullptr, &st3));  // LN3 folded
   b.release_stats(st3);
   // ff.net.2 (+ y3) and proj_out (+ x) are two Linears with only a residual add between them: one GEMM over [f | y3]

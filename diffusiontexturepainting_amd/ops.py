@@ -225,6 +225,19 @@ def xattn(x, w1, b1, lns1, st_in, w2, b2, n_samples, sm_valid=14, ln_eps=1e-5, r
     return (y, st) if row_stats else y
 
 
+def xchain(a, wo, bo, y, w1, b1, lns1, w2, b2, n_samples, sm_valid=14, ln_eps=1e-5, row_stats=False):
+    """Register-chained out-projection + cross-attention (xchain.hip): a / y f16 [N*S, C = 320]; wo packed f16 [rows, ldw]; w1 / b1 / lns1 / w2 /
+    b2 as for xattn() -> y3 f16 [N*S, C] (and the [N*S, 2] row statistics of y3)."""
+    lib = _lib.load()
+    rows, c = a.shape
+    s = rows // n_samples
+    y3 = torch.empty_like(a)
+    st = torch.zeros(rows, 2, dtype=torch.float32, device=a.device) if row_stats else None
+    check(lib.dtp_op_xchain(ptr(a), ptr(wo), wo.shape[1], ptr(bo), ptr(y), ptr(w1), ptr(b1), ptr(lns1), ptr(w2), ptr(b2), ptr(y3), ptr(st), s, c,
+                            n_samples, sm_valid, ln_eps, _stream()), "xchain")
+    return (y3, st) if row_stats else y3
+
+
 def gn_fold_weights(x, wp, n_out, bias, gamma, beta, groups=32, eps=1e-6):
     """x f16 [B,HW,C], wp packed f16 [rows, ldw] -> (per-sample packed weights f16 [B, rows, ldw], biases f32 [B, rows]) such that
     proj(GroupNorm(x_b)) == x_b @ W_b^T + b_b (GroupNorm without activation folded into its consumer)."""
@@ -236,6 +249,18 @@ def gn_fold_weights(x, wp, n_out, bias, gamma, beta, groups=32, eps=1e-6):
     check(lib.dtp_op_gn_fold_weights(ptr(x), ptr(wp), wp.shape[1], ptr(bias), ptr(gamma), ptr(beta), b, hw, c, n_out, groups, eps, ptr(wout), ptr(bout),
                                      _stream()), "gn_fold_weights")
     return wout, bout
+
+
+def gn_linear(x, wp, n_out, bias, gamma, beta, groups=32, eps=1e-6, col_ranges=4, row_stats=False):
+    """x f16 [B,HW,C] (C in {320, 640}, HW % 128 == 0), wp packed f16 [rows, ldw] -> y f16 [B,HW,n_out] = proj(GroupNorm(x)) in one launch
+    behind the statistics pass: the GroupNorm is applied to the resident activation fragments of lnlin_kernel (no fold, no apply pass)."""
+    lib = _lib.load()
+    b, hw, c = x.shape
+    y = torch.empty(b, hw, n_out, dtype=torch.float16, device=x.device)
+    st = torch.zeros(col_ranges, b * hw, 2, dtype=torch.float32, device=x.device) if row_stats else None
+    check(lib.dtp_op_gn_linear(ptr(x), ptr(wp), wp.shape[1], ptr(bias), ptr(gamma), ptr(beta), b, hw, c, n_out, groups, eps, ptr(y), ptr(st),
+                               col_ranges, _stream()), "gn_linear")
+    return (y, st) if row_stats else y
 
 
 def layernorm(x, gamma, beta, eps=1e-5):

@@ -259,11 +259,25 @@ int dtp_op_xattn(const void* X, const void* W1, const float* b1, const float* ln
 /* the same with an explicit number of 128-column tiles per workgroup (ct >= 1; ct < 1 = the launcher's rule, i.e. the call above) */
 int dtp_op_xattn_ct(const void* X, const void* W1, const float* b1, const float* lns1, const float* st_in, int st_parts, const void* W2, const float* b2,
                     const void* R, void* Y, float* st_out, int S, int C, int N, int sm_valid, float ln_eps, int ct, dtp_stream s);
+/* attn1.to_out.0 + residual, LayerNorm-2 and the fused cross-attention pair above as ONE register-chained launch (round 6, xchain.hip;
+ * BasicTransformerBlock of diffusers 0.12 as run by the UNet engine, models.py:1097-1139):
+ *   Y2 = A Wo^T + bo + Y;  Y3 = softmax_16(LN(Y2) W1^T + b1) W2^T + b2 + Y2   per sample -- Y2 and its row statistics never leave registers.
+ * A / Y / Y3 f16 [N*S][C]; Wo f16 packed [>= C][ldwo] (dtp_op_pack_linear); W1 / b1 / lns1 / W2 / b2 as for dtp_op_xattn; st_out f32 [N*S][2]
+ * (or null) = per-row (sum, sumsq) of Y3, ONE partial per row.  C == 320, S % 128 == 0 (UNet level 0). */
+int dtp_op_xchain(const void* A, const void* Wo, int ldwo, const float* bo, const void* Y, const void* W1, const float* b1, const float* lns1,
+                  const void* W2, const float* b2, void* Y3, float* st_out, int S, int C, int N, int sm_valid, float ln_eps, dtp_stream s);
 /* GroupNorm (no activation) folded into the Linear / 1x1 conv that consumes it (Transformer2DModel: norm -> proj_in): from x f16
  * [B][HW][C] and the packed weights W f16 [rows][ldw] (+ bias[Nout]) compute per-sample Wout f16 [B][rows][ldw] = W diag(gamma * rstd_b)
  * and bias_out f32 [B][rows] = bias + W (beta - mean_b * rstd_b * gamma), rows = roundup(Nout, 128): proj(GN(x_b)) == Wout_b x_b + bias_out_b */
 int dtp_op_gn_fold_weights(const void* x, const void* W, int ldw, const float* bias, const float* gamma, const float* beta, int B, int HW, int C,
                            int Nout, int groups, float eps, void* Wout, float* bias_out, dtp_stream s);
+/* the same pair WITHOUT the fold (round 6): y f16 [B*HW][Nout] = W GroupNorm(x_b) + bias with the normalisation applied to the resident
+ * activation fragments of the activation-stationary Linear (lnlin_kernel, GNA build): statistics pass + ONE launch on the raw tensor and
+ * the shared weights W f16 [rows][ldw] (dtp_op_pack_linear).  C in {320, 640}, HW % 128 == 0, 32 groups; col_ranges = workgroups per
+ * 128-row block (>= 1).  st_out (or null): f32 [col_ranges][B*HW][2] per-row (sum, sumsq) partials of y for a LayerNorm-folded consumer.
+ * Replaces models.py Transformer2DModel norm -> proj_in (diffusers 0.12) at UNet levels 0-1. */
+int dtp_op_gn_linear(const void* x, const void* W, int ldw, const float* bias, const float* gamma, const float* beta, int B, int HW, int C,
+                     int Nout, int groups, float eps, void* y, float* st_out, int col_ranges, dtp_stream s);
 int dtp_op_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int rows, int C,
                      float eps, dtp_stream s);
 int dtp_op_attention(const void* Q, const void* K, const void* V, void* O, int ldq, int ldk, int ldv, int ldo, int B, int H,

@@ -20,7 +20,7 @@ def _stub_line(bench, n_kernels=40):
     rows = [{"kernel": f"{k}<{i}, 16, 1, 2, false, true, a_rather_long_template_argument>", "launches": 100 + i, "ms": 1.0 + 0.123456789 * i,
              "flops": 2e10 * (i + 1), "bytes": 1e8 * (i + 1)} for i in range(n_kernels) for k in bench.CONTRACTION_KERNELS[:1]]
     rows += [{"kernel": k, "launches": 10, "ms": 2.5, "flops": 2e12, "bytes": 1e9} for k in bench.CONTRACTION_KERNELS[1:]]
-    rows += [{"kernel": "gn_apply_kernel<true>", "launches": 451, "ms": 3.8, "flops": 0, "bytes": 4e9}]
+    rows += [{"kernel": "groupnorm (gn_stats+gn_apply | gn_fused)", "launches": 451, "ms": 3.8, "flops": 0, "bytes": 4e9}]
     classes = {"m_classes": [{"M": 12288, "launches": 500, "ms": 30.0, "tflops": 700.0}] * 12, "groupnorm_small_maps": {"launches": 1, "ms": 0.1},
                "groupnorm_large_maps": {"launches": 2, "ms": 0.2}, "standalone_splitk_reduce_launches": 3}
     roof, detail = bench.roofline_record(rows, classes, 1, 512, 20, 0.094, 1700.0, 4900.0)

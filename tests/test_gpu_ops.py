@@ -358,6 +358,44 @@ def test_fused_cross_attention_several_column_tiles_per_workgroup(ops, nb, s, c,
     assert torch.equal(got_y, ref_y) and torch.equal(got_st, ref_st)
 
 
+@pytest.mark.parametrize("nb,s", [(3, 4096), (1, 128), (2, 1024), (24, 256)])
+def test_register_chained_out_projection_and_cross_attention(ops, nb, s):
+    """xchain_kernel: y2 = a Wo^T + bo + y, P = softmax_14of16(LN(y2) W1^T + b1) per head group, y3 = P W2^T + b2 + y2 in ONE launch with y2,
+    its LayerNorm statistics and P held in registers (the accumulator of one MFMA contraction is the B operand of the next, the weight
+    fragments of the chained contractions are read in the permuted k order).  Against torch in fp32, and against the two launches it replaces
+    (plain Linear with residual + row statistics, then the fused cross-attention pair) within fp16 rounding; the row statistics it emits for
+    the LayerNorm-folded FF1 must be those of the stored y3."""
+    c = 320
+    g = torch.Generator().manual_seed(377)
+    a = (rnd(nb * s, c, seed=378) * 1.2).cuda()
+    y = (rnd(nb * s, c, seed=379) * 1.3 + 0.2).cuda()
+    wo = rnd(c, c, seed=380, scale=c ** -0.5).float()
+    bo = 0.2 * torch.randn(c, generator=g)
+    w1 = rnd(nb, 128, c, seed=381, scale=2.0 * c ** -0.5).float()
+    b1 = 0.3 * torch.randn(nb, 128, generator=g)
+    w2 = rnd(nb, c, 128, seed=382, scale=0.1).float()
+    b2 = torch.randn(c, generator=g)
+    # fp32 reference
+    y2 = (a.float().cpu() @ wo.t() + bo + y.float().cpu()).half().float()
+    ln = F.layer_norm(y2, (c,), eps=1e-5).view(nb, s, c)
+    sc = torch.einsum("bsc,bnc->bsn", ln, w1) + b1[:, None, :]
+    pm = torch.zeros_like(sc).view(nb, s, 8, 16)
+    pm[..., :14] = torch.softmax(sc.view(nb, s, 8, 16)[..., :14], dim=-1)
+    ref = torch.einsum("bsn,bcn->bsc", pm.view(nb, s, 128).half().float(), w2).reshape(nb * s, c) + b2 + y2
+    wop = ops.pack_linear(wo.cuda())
+    w1p = torch.cat([ops.pack_linear(w1[b].cuda()) for b in range(nb)], dim=0).contiguous()
+    lns = ops.rowsum(w1p, c)
+    w2p = torch.cat([ops.pack_linear(w2[b].cuda()) for b in range(nb)], dim=0).contiguous()
+    got, st = ops.xchain(a, wop, bo.cuda(), y, w1p, b1.reshape(-1).cuda(), lns, w2p, b2.cuda(), nb, row_stats=True)
+    close(got, ref, tol=3e-3)
+    gf = got.float().cpu()
+    assert torch.allclose(st[:, 0].cpu(), gf.sum(dim=1), rtol=1e-4, atol=1e-2) and torch.allclose(st[:, 1].cpu(), (gf * gf).sum(dim=1), rtol=1e-4, atol=1e-2)
+    # the two launches it replaces
+    y2g, st2 = ops.gemm(a, wop, c, c, bias=bo.cuda(), resid=y, tile=50, splits=5, row_stats=True)
+    two = ops.xattn(y2g, w1p, b1.reshape(-1).cuda(), lns, st2[:5].contiguous(), w2p, b2.cuda(), nb)
+    close(got, two.float().cpu(), tol=3e-3)
+
+
 def test_gemm_batched_residual(ops):
     """Second half: P [b*M, 128] times a per-entry [N, 128] matrix, + bias + residual."""
     nb, m, n = 3, 130, 320
@@ -607,6 +645,28 @@ def test_conv3x3_strided_view_and_f32_out(ops):
     close(got, ref, tol=1e-3)
 
 
+@pytest.mark.parametrize("tile", [53, 54])
+def test_conv_epilogue_statistics_with_a_large_output_mean(ops, tile):
+    """GF_GNSTATS with conv outputs whose group means are ~150 standard deviations away from zero (a large bias): the statistics the
+    epilogue emits -- fp64 from the lane butterflies on since round 6 -- must still give the GroupNorm of the STORED tensor (fp64 reference
+    on the fp16 conv output)."""
+    b, h, cin, cout = 2, 32, 128, 320
+    x = rnd(b, h, h, cin, seed=183)
+    wt = rnd(cout, cin, 3, 3, seed=184, scale=(9 * cin) ** -0.5)
+    g = torch.Generator().manual_seed(185)
+    bias = 150.0 * (1 + 0.1 * torch.rand(32, generator=g)).repeat_interleave(cout // 32)
+    wf = wt.float().cuda()
+    y, st = ops.conv3x3(x.cuda(), ops.pack_conv(wf), cout, bias=bias.cuda(), wfr=ops.pack_conv_ws(wf), tile=tile, splits=1, gn_groups=32)
+    gamma, beta = (1 + 0.2 * torch.randn(cout, generator=g)).cuda(), (0.2 * torch.randn(cout, generator=g)).cuda()
+    z = ops.groupnorm_apply(y, gamma, beta, st, eps=1e-5, silu=False)
+    yd = y.double().cpu()
+    assert 50 < (yd.mean() / yd.reshape(b, -1, 32, cout // 32).std(dim=(1, 3)).mean()).item()  # the case is what it says
+    ref = F.group_norm(yd.permute(0, 3, 1, 2), 32, gamma.double().cpu(), beta.double().cpu(), eps=1e-5).permute(0, 2, 3, 1)
+    err = (z.double().cpu() - ref).abs().max().item()
+    print("conv-epilogue statistics, large mean: max abs err", err)
+    assert err <= 6e-3
+
+
 @pytest.mark.parametrize("b,hw,c,silu,eps", [(3, 64, 320, True, 1e-5), (2, 256, 640, False, 1e-6), (1, 1024, 128, True, 1e-6),
                                              (2, 16, 1920, True, 1e-5), (1, 100, 2560, True, 1e-5), (2, 64, 256, True, 1e-6),
                                              (1, 64, 512, False, 1e-6), (3, 4, 960, True, 1e-5), (1, 4096, 320, True, 1e-5),
@@ -620,6 +680,37 @@ def test_groupnorm(ops, b, hw, c, silu, eps):
         ref = F.silu(ref)
     got = ops.groupnorm(x.cuda(), gamma.cuda(), beta.cuda(), eps=eps, silu=silu)
     close(got, ref)
+
+
+# |group mean| / group sigma -> allowed max abs error of the normalised output (|y| <= ~4; one fp16 step there is 2e-3..4e-3)
+GN_LARGE_MEAN_BOUNDS = {0: 3e-3, 50: 3e-3, 300: 1.5e-2}
+
+
+@pytest.mark.parametrize("k", [0, 50, 300])
+@pytest.mark.parametrize("b,hw,c", [(3, 4096, 320), (3, 1024, 640), (3, 256, 1280), (3, 64, 1280), (1, 16384, 128)])
+def test_groupnorm_large_group_means(ops, b, hw, c, k):
+    """Round-5 verdict: every GroupNorm variance in norm.hip was E[x^2] - mean^2 from fp32 sums and no test fed |mean| >> sigma.  Inputs
+    whose 32 group means are k sigma (k = 0 / 50 / 300, one sign) through the two-launch GroupNorm (statistics pass + apply), the
+    single-launch form of the small maps and the reduce-in-GroupNorm forms, against an fp64 reference on the same fp16 tensor.
+    Measured with the fp32 sums of rounds 1-5 (profiles/r06_gn_large_mean_before.log): 3.7e-3 at 50 sigma, 7e-2 .. 1.1e-1 at 300 sigma, O(1) at
+    1000 sigma.  Round 6: every sum above a thread's own few elements, the totals over the chunks and E[x^2] - mean^2 itself run in fp64 (and the
+    element count is exact, not a rounded reciprocal): 2.1e-3 at 50 sigma (one fp16 step of the output), <= 9.3e-3 at 300 sigma, 1.2e-1 at 1000
+    sigma (profiles/r06_gn_large_mean_after.log).  What is left at 300 sigma is the fp32 STORAGE of the per-chunk partial sums between the
+    statistics and the apply launch (2^-24 of a sum of squares that is 9e4 x the variance); carrying those in two floats would remove it --
+    not done: no GroupNorm input of these networks is expected to sit hundreds of group standard deviations away from zero."""
+    sigma = 0.05
+    g = torch.Generator().manual_seed(7 + k)
+    grp_mean = k * sigma * (1 + 0.2 * torch.rand(32, generator=g))
+    x = (grp_mean.repeat_interleave(c // 32) + sigma * torch.randn(b, hw, c, generator=g)).half()
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    ref = F.group_norm(x.double().permute(0, 2, 1), 32, gamma.double(), beta.double(), 1e-5).permute(0, 2, 1)
+    got = ops.groupnorm(x.cuda(), gamma.cuda(), beta.cuda(), eps=1e-5, silu=False).double().cpu()
+    part = torch.stack([x.float() * 0.5, x.float() * 0.5]).contiguous()  # the same tensor as two fp32 split-K slabs (exact halves)
+    out, y = ops.reduce_groupnorm(part.cuda(), gamma.cuda(), beta.cuda(), silu=False)
+    assert torch.equal(out.cpu(), x)
+    e1, e2 = (got - ref).abs().max().item(), (y.double().cpu() - ref).abs().max().item()
+    print(f"k={k} B={b} HW={hw} C={c}: groupnorm {e1:.2e}, reduce+groupnorm {e2:.2e}")
+    assert e1 <= GN_LARGE_MEAN_BOUNDS[k] and e2 <= GN_LARGE_MEAN_BOUNDS[k]
 
 
 @pytest.mark.parametrize("hw,c", [(4096, 320), (4096, 640), (1024, 1280), (4096, 960), (256, 1280), (16384, 128)])
@@ -711,6 +802,33 @@ def test_groupnorm_folded_into_linear(ops, b, hw, c, n):
     wf, bf = ops.gn_fold_weights(x.cuda(), wp, n, bias.cuda(), gamma.cuda(), beta.cuda())
     got = ops.gemm(x.cuda().view(b * hw, c), wf.view(-1, wf.shape[-1]), n, c, bias=bf.view(-1), flags=GF_BIAS, batch=b)
     close(got.view(b, hw, n), ref, tol=4e-3)
+
+
+@pytest.mark.parametrize("b,hw,c,n,ranges", [(3, 4096, 320, 320, 5), (3, 1024, 640, 640, 4), (2, 1024, 320, 320, 1), (1, 256, 640, 640, 10),
+                                              (8, 128, 320, 320, 3), (3, 1024, 640, 320, 2)])
+def test_groupnorm_applied_on_the_resident_fragments_of_the_linear(ops, b, hw, c, n, ranges):
+    """Round 6: proj_in(GroupNorm(x)) WITHOUT per-sample folded weights -- lnlin_kernel<.., GNA> normalises its resident activation fragments
+    from the statistics partials (fp32 fma per element, as gn_apply_kernel) and streams the shared weight matrix: statistics pass + one
+    launch.  Against torch in fp32 (x carries per-channel offsets and a group mean of several sigma), against the two-step path
+    GroupNorm launch -> plain Linear (bit-identical: same statistics, same per-element arithmetic, same MFMA order), and the row
+    statistics it emits for the LayerNorm-folded q / k / v projection."""
+    g = torch.Generator().manual_seed(147)
+    x = (rnd(b, hw, c, seed=148).float() * 1.5 + 0.8 * torch.randn(c, generator=g) + 3.0).half()
+    w = rnd(n, c, seed=149, scale=c ** -0.5).float()
+    bias = 0.1 * torch.randn(n, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    ref = F.linear(F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, 1e-6).permute(0, 2, 1), w, bias)
+    wp = ops.pack_linear(w.cuda())
+    got, st = ops.gn_linear(x.cuda(), wp, n, bias.cuda(), gamma.cuda(), beta.cuda(), col_ranges=ranges, row_stats=True)
+    close(got, ref, tol=4e-3)
+    if hw >= 1024:  # (below, GroupNorm alone is the single-launch kernel, whose per-element arithmetic is (x - mean) rstd gamma + beta)
+        from diffusiontexturepainting_amd._lib import GF_BIAS
+        xn = ops.groupnorm(x.cuda(), gamma.cuda(), beta.cuda(), eps=1e-6, silu=False)
+        two = ops.gemm(xn.view(b * hw, c), wp, n, c, bias=bias.cuda(), flags=GF_BIAS, tile=50, splits=ranges)
+        assert torch.equal(got.view(b * hw, n), two)
+    gf = got.float().view(b * hw, n).cpu()
+    tot = st.sum(dim=0).cpu()
+    assert torch.allclose(tot[:, 0], gf.sum(dim=1), rtol=1e-4, atol=1e-2) and torch.allclose(tot[:, 1], (gf * gf).sum(dim=1), rtol=1e-4, atol=1e-2)
 
 
 @pytest.mark.parametrize("rows,c", [(1000, 320), (333, 640), (64, 1280), (14, 768), (5, 2048)])
