@@ -102,6 +102,7 @@ SYMBOLS = {
     "dtp_op_reduce_groupnorm_cx": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "dtp_op_xattn_ct": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "dtp_op_gn_fold_weights": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "dtp_op_ffchain": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "dtp_op_xchain": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "dtp_op_gn_linear": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
     "dtp_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),

@@ -241,6 +241,20 @@ int dtp_op_gn_linear(const void* x, const void* W, int ldw, const float* bias, c
   return dtp_launch_lnlin(p, col_ranges >= 1 ? col_ranges : 4, (hipStream_t)s);
 }
 
+int dtp_op_ffchain(const void* X, const void* W1, int ldw1, const float* lns1, const float* b1, const void* Wm, int ldwm, const float* bm,
+                   const void* R, void* Out, int M, int C, float ln_eps, dtp_stream s) {
+  std::lock_guard<std::mutex> lk(g_ops_mu);
+  int rc = ops_init();
+  if (rc) return rc;
+  static bool init = false;
+  if (!init) { dtp_ffchain_init(); init = true; }
+  FfchainParams p = {};
+  p.X = (const f16*)X; p.ldx = C; p.W1 = (const f16*)W1; p.ldw1 = ldw1; p.lns1 = lns1; p.b1 = b1;
+  p.Wm = (const f16*)Wm; p.ldwm = ldwm; p.bm = bm; p.R = (const f16*)R; p.ldr = C; p.Out = (f16*)Out; p.ldo = C;
+  p.M = M; p.C = C; p.ln_eps = ln_eps;
+  return dtp_launch_ffchain(p, (hipStream_t)s);
+}
+
 int dtp_op_xchain(const void* A, const void* Wo, int ldwo, const float* bo, const void* Y, const void* W1, const float* b1, const float* lns1,
                   const void* W2, const float* b2, void* Y3, float* st_out, int S, int C, int N, int sm_valid, float ln_eps, dtp_stream s) {
   std::lock_guard<std::mutex> lk(g_ops_mu);

@@ -359,6 +359,23 @@ bool dtp_xchain_supported(const XchainParams& p);
 int dtp_launch_xchain(const XchainParams& p, hipStream_t s);
 void dtp_xchain_init();
 
+// ---------------------------------------------------------------- register-chained feed-forward (ffchain.hip)
+// Out = [GEGLU(LN(X) W1^T + b1) | X] Wm^T + bm + R, C = 320 (hidden 1280); the hidden tensor stays in registers
+struct FfchainParams {
+  const f16* X; int ldx;             // y3 rows [M][C] (raw: LayerNorm-3 folded into W1 / lns1 / b1)
+  const f16* W1; int ldw1;           // ff.net.0.proj packed [2 H][ldw1] in the GEGLU row packing (a(64) | gate(64) per 128 rows), gamma folded in
+  const float *lns1, *b1;            // [2 H] row sums of W1 and bias (+ W beta), indexed by packed row
+  const f16* Wm; int ldwm;           // merged [ff.net.2 | proj_out] weights packed [>= C][ldwm], K = H + C (unet.hip load_linear_pair)
+  const float* bm;                   // [C] or null
+  const f16* R; int ldr;             // residual rows (the block input) or null
+  f16* Out; int ldo;
+  int M, C;
+  float ln_eps;
+};
+bool dtp_ffchain_supported(const FfchainParams& p);
+int dtp_launch_ffchain(const FfchainParams& p, hipStream_t s);
+void dtp_ffchain_init();
+
 // ---------------------------------------------------------------- elementwise / layout (elementwise.hip)
 int dtp_launch_concat_channels(const f16* a, int lda, int Ca, const f16* b, int ldb, int Cb, f16* y, int ldy, long long rows,
                                hipStream_t s);

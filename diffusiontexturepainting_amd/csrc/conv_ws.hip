@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
     }
   }
 
-  // ---- the four partial tiles -> LDS, block (wave, tile, register group q) = 64 x 16 bytes at a 1152-byte pitch, slot 2 * pixel + half:
+  // ---- the four partial tiles -> LDS, block (wave, tile, register group q) = 64 x 16 bytes at a 1152-byte pitch, slot (2 * pixel + half) ^ ((pixel >> 2) & 1):
   // thread t of pass (i, j) then sums the four waves' values of (pixel t / 8 of tile j, channels 4 (t % 8) .. of n-tile i) -- conflict-
   // free for the lane groups of ds_read_b128 (tests/test_conv_ws_layout.py) -- and eight neighbouring lanes store one pixel's 128
   // contiguous bytes.
@@ -410,7 +410,12 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
   constexpr int RT = CO ? 1 : NT;        // n-tiles per combine round
   const int epx = tid >> 3, c4 = tid & 7;            // pixel inside the tile, channel quad
   const int epxl = epx % TW, epyl = epx / TW;
-  const char* const src0 = smem + (c4 >> 1) * CB + (epx * 2 + (c4 & 1)) * 16;
+  // slot of (pixel, half) inside a 1 KB block: (2 pixel + half) ^ ((pixel >> 2) & 1).  The plain 2 pixel + half is conflict-free for the
+  // READS below (16-lane groups, 64 banks) but 2-way conflicted for the WRITES (ds_write_b128: groups of 8 consecutive lanes, 32 banks --
+  // eight lanes 32 bytes apart cover 128 bytes twice): that was every conflict cycle SQ_LDS_BANK_CONFLICT counted in this kernel
+  // (profiles/r05_pmc_unet_mfma.json: 468 k cycles per launch = 480 workgroups x 4 waves x 32 stores x 8 extra cycles; round-5 verdict,
+  // item 4).  The XOR keeps both sides conflict-free (tests/test_conv_ws_layout.py).
+  const char* const src0 = smem + (c4 >> 1) * CB + ((epx * 2 + (c4 & 1)) ^ ((epx >> 2) & 1)) * 16;
   // GF_GNSTATS (unsplit launches of the two-n-tile builds): the GroupNorm that consumes this conv's output gets its statistics from
   // here -- per (pixel tile, group) sums of the ROUNDED fp16 outputs -- instead of from a pass of its own over the tensor.
   constexpr bool CAN_STATS = G::STATB > 0;
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(256, CO ? 2 : 1) void convws_kernel(const GemmParam
   for (int i0 = 0; i0 < NT; i0 += RT) {
     if (i0 > 0) __syncthreads();  // the previous round's reads are done
     {
-      char* const mine = smem + wave * RT * TM * 4 * CB + (frow * 2 + fhalf) * 16;
+      char* const mine = smem + wave * RT * TM * 4 * CB + ((frow * 2 + fhalf) ^ ((frow >> 2) & 1)) * 16;
 #pragma unroll
       for (int i = 0; i < RT; ++i)
 #pragma unroll

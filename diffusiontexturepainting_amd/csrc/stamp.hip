@@ -339,6 +339,7 @@ int dtp_finalize_weights(dtp_ctx* ctx) {
   dtp_xattn_init();
   dtp_lnlin_init();
   dtp_xchain_init();
+  dtp_ffchain_init();
   dtp_conv_ws_init();
   dtp_gemm_ws_init();
   RC(load_unet_weights(c));

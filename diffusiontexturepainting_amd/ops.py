@@ -238,6 +238,17 @@ def xchain(a, wo, bo, y, w1, b1, lns1, w2, b2, n_samples, sm_valid=14, ln_eps=1e
     return (y3, st) if row_stats else y3
 
 
+def ffchain(x, w1, lns1, b1, wm, bm, resid=None, ln_eps=1e-5):
+    """Register-chained feed-forward (ffchain.hip): x f16 [M, 320]; w1 packed (geglu) f16 [2560, ldw] with lns1 / b1 f32 [2560] by packed row; wm
+    packed f16 [rows, 1600] = the merged [ff.net.2 | proj_out] weights -> out f16 [M, 320] = [GEGLU(LN(x) w1^T + b1) | x] wm^T + bm + resid."""
+    lib = _lib.load()
+    m, c = x.shape
+    out = torch.empty_like(x)
+    check(lib.dtp_op_ffchain(ptr(x), ptr(w1), w1.shape[1], ptr(lns1), ptr(b1), ptr(wm), wm.shape[1], ptr(bm), ptr(resid), ptr(out), m, c, ln_eps,
+                             _stream()), "ffchain")
+    return out
+
+
 def gn_fold_weights(x, wp, n_out, bias, gamma, beta, groups=32, eps=1e-6):
     """x f16 [B,HW,C], wp packed f16 [rows, ldw] -> (per-sample packed weights f16 [B, rows, ldw], biases f32 [B, rows]) such that
     proj(GroupNorm(x_b)) == x_b @ W_b^T + b_b (GroupNorm without activation folded into its consumer)."""

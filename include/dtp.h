@@ -266,6 +266,13 @@ int dtp_op_xattn_ct(const void* X, const void* W1, const float* b1, const float*
  * (or null) = per-row (sum, sumsq) of Y3, ONE partial per row.  C == 320, S % 128 == 0 (UNet level 0). */
 int dtp_op_xchain(const void* A, const void* Wo, int ldwo, const float* bo, const void* Y, const void* W1, const float* b1, const float* lns1,
                   const void* W2, const float* b2, void* Y3, float* st_out, int S, int C, int N, int sm_valid, float ln_eps, dtp_stream s);
+/* the feed-forward of a transformer block as ONE register-chained launch (round 6, ffchain.hip): Out = [GEGLU(LN(X) W1^T + b1) | X] Wm^T +
+ * bm + R with the [M][4 C] hidden tensor held in registers.  X / R / Out f16 [M][C]; W1 f16 packed [8 C][ldw1] in the GEGLU row packing
+ * (dtp_op_pack_linear geglu = 1) with the LayerNorm gamma folded in, lns1 / b1 f32 indexed by packed row; Wm f16 packed [>= C][ldwm],
+ * K = 4 C (hidden) + C (X): the merged ff.net.2 / proj_out weights.  C == 320.  Replaces ff.net.0 / ff.net.2 / proj_out of
+ * BasicTransformerBlock + Transformer2DModel (diffusers 0.12; models.py:1097-1139), SURVEY K4. */
+int dtp_op_ffchain(const void* X, const void* W1, int ldw1, const float* lns1, const float* b1, const void* Wm, int ldwm, const float* bm,
+                   const void* R, void* Out, int M, int C, float ln_eps, dtp_stream s);
 /* GroupNorm (no activation) folded into the Linear / 1x1 conv that consumes it (Transformer2DModel: norm -> proj_in): from x f16
  * [B][HW][C] and the packed weights W f16 [rows][ldw] (+ bias[Nout]) compute per-sample Wout f16 [B][rows][ldw] = W diag(gamma * rstd_b)
  * and bias_out f32 [B][rows] = bias + W (beta - mean_b * rstd_b * gamma), rows = roundup(Nout, 128): proj(GN(x_b)) == Wout_b x_b + bias_out_b */

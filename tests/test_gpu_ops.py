@@ -396,6 +396,43 @@ def test_register_chained_out_projection_and_cross_attention(ops, nb, s):
     close(got, two.float().cpu(), tol=3e-3)
 
 
+@pytest.mark.parametrize("m", [12288, 128, 300, 1000])
+def test_register_chained_feed_forward(ops, m):
+    """ffchain_kernel: out = [GEGLU(LN(x) W1^T + b1) | x] Wm^T + bm + r with the [M, 1280] hidden tensor held in registers (FF1's
+    accumulators become FF2's B operand, pair of 32-column chunks by pair).  Against torch in fp32 (hidden rounded to fp16 where the kernel
+    rounds it), and against the two launches it replaces (lnlin GEGLU, then the K = 1600 GEMM over [h | x]); ragged last row block."""
+    from diffusiontexturepainting_amd._lib import GF_BIAS, GF_GEGLU
+    c, hdim = 320, 1280
+    g = torch.Generator().manual_seed(477)
+    x = rnd(m, c, seed=478) * 1.7 + 0.4
+    r = rnd(m, c, seed=479)
+    w1 = rnd(2 * hdim, c, seed=480, scale=c ** -0.5).float()
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    b1 = 0.1 * torch.randn(2 * hdim, generator=g)
+    wm = rnd(c, hdim + c, seed=481, scale=(hdim + c) ** -0.5).float()
+    bm = 0.1 * torch.randn(c, generator=g)
+    pre = F.linear(F.layer_norm(x.float(), (c,), gamma, beta, 1e-5), w1, b1)
+    a, gate = pre.chunk(2, dim=-1)
+    h = (a * F.gelu(gate)).half().float()
+    ref = F.linear(torch.cat([h, x.float()], dim=-1), wm, bm) + r.float()
+    # packed operands: GEGLU row packing for W1 (and its bias), LayerNorm gamma folded into W1, beta into the bias
+    b1f = b1 + w1 @ beta
+    f = torch.arange(hdim)
+    perm = torch.empty(2 * hdim, dtype=torch.long)
+    perm[f] = (f // 64) * 128 + f % 64
+    perm[hdim + f] = (f // 64) * 128 + 64 + f % 64
+    b1p = torch.empty_like(b1f)
+    b1p[perm] = b1f
+    w1p = ops.pack_linear((w1 * gamma[None]).cuda(), geglu=True)
+    lns = ops.rowsum(w1p, c)
+    wmp = ops.pack_linear(wm.cuda())
+    got = ops.ffchain(x.cuda(), w1p, lns, b1p.cuda(), wmp, bm.cuda(), resid=r.cuda())
+    close(got, ref, tol=4e-3)
+    hg = ops.gemm(x.cuda(), w1p, 2 * hdim, c, bias=b1p.cuda(), lns=lns, tile=50, splits=5, flags=GF_GEGLU | GF_BIAS)
+    two = ops.gemm(hg, wmp, c, hdim, bias=bm.cuda(), resid=r.cuda(), tail=x.cuda())
+    close(got, two.float().cpu(), tol=4e-3)
+
+
 def test_gemm_batched_residual(ops):
     """Second half: P [b*M, 128] times a per-entry [N, 128] matrix, + bias + residual."""
     nb, m, n = 3, 130, 320
