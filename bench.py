@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 CONTRACTION_KERNELS = ("gemm_kernel", "conv_halo_kernel", "gemm_wide_kernel", "xattn_kernel", "xchain_kernel", "lnlin_kernel", "convws_kernel")
-PMC_TRAFFIC_FILE = "r05_pmc_unet_traffic.json"  # tools/pmc_unet.sh, committed with the sha1 of the kernel sources it was collected on
+PMC_TRAFFIC_FILE = "r06_pmc_unet_traffic.json"  # tools/pmc_unet.sh, committed with the sha1 of the kernel sources it was collected on
 
 
 def cpu_baseline(res, ddim_steps, weights, budget_note):
@@ -103,11 +103,11 @@ def pmc_traffic(batch):
             "traffic_source": f"profiles/{PMC_TRAFFIC_FILE}", "traffic_kernel_source_hash": t["kernel_source_hash"]}
 
 
-PMC_MFMA_FILE = "r05_pmc_unet_mfma.json"  # tools/pmc_unet_mfma.sh + tools/pmc_mfma_json.py, same source-hash rule as the traffic record
+PMC_MFMA_FILE = "r06_pmc_unet_mfma.json"  # tools/pmc_unet_mfma.sh + tools/pmc_mfma_json.py, same source-hash rule as the traffic record
 
 
 def pmc_mfma():
-    """MFMA-busy of the contraction kernels from the committed SQ counter pass (profiles/r05_pmc_unet_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES
+    """MFMA-busy of the contraction kernels from the committed SQ counter pass (profiles/r06_pmc_unet_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES
     over 1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs, per kernel and for the class, over three eager UNet evaluations).  Like `traffic`: only
     reported when the record was collected on the kernel sources this library was built from."""
     path = os.path.join(ROOT, "profiles", PMC_MFMA_FILE)

@@ -10,7 +10,7 @@ spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "b
 bench = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bench)
 
-GEMM = ("gemm_kernel<", "conv_halo_kernel<", "gemm_wide_kernel<", "xattn_kernel", "lnlin_kernel<", "convws_kernel<")
+GEMM = ("gemm_kernel<", "conv_halo_kernel<", "gemm_wide_kernel<", "xattn_kernel", "xchain_kernel", "ffchain_kernel", "lnlin_kernel<", "convws_kernel<")
 WATCH = GEMM + ("attn_dma_kernel<", "attention_kernel<", "gn_apply_kernel", "gn_reduce_fused_kernel", "gn_stats")
 
 
@@ -45,7 +45,7 @@ for k, c in sorted(p1.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", (0, 
 rec = {
     "what": "SQ counters per kernel over 3 eager UNet evaluations at 512^2, batch 3 (tools/pmc_unet_mfma.sh: two separate rocprofv3 --pmc passes, no tracing)",
     "class_mfma_busy": cls_busy / (1024.0 * cls_cyc) if cls_cyc else None,
-    "class": "gemm_kernel + conv_halo_kernel + gemm_wide_kernel + convws_kernel + lnlin_kernel + xattn_kernel (all instantiations)",
+    "class": "gemm_kernel + conv_halo_kernel + gemm_wide_kernel + convws_kernel + lnlin_kernel + xattn_kernel + xchain_kernel (all instantiations)",
     "per_kernel": per[:24],
     "kernel_source_hash": bench.kernel_source_hash(),
 }

@@ -8,7 +8,7 @@ spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "b
 bench = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bench)
 
-GEMM = ("gemm_kernel<", "conv_halo_kernel<", "gemm_wide_kernel<", "xattn_kernel", "lnlin_kernel<", "convws_kernel<")
+GEMM = ("gemm_kernel<", "conv_halo_kernel<", "gemm_wide_kernel<", "xattn_kernel", "xchain_kernel", "ffchain_kernel", "lnlin_kernel<", "convws_kernel<")
 
 
 def total(path, counter):
@@ -23,7 +23,7 @@ nf, fetch = total(sys.argv[1], "FETCH_SIZE")
 nw, write = total(sys.argv[2], "WRITE_SIZE")
 assert nf == nw and nf > 0, (nf, nw)
 rec = {
-    "what": "HBM-side traffic of the implicit-GEMM kernel class (gemm_kernel<...> + conv_halo_kernel<...> + gemm_wide_kernel<...> + convws_kernel<...> + lnlin_kernel<...> + xattn_kernel, all "
+    "what": "HBM-side traffic of the implicit-GEMM kernel class (gemm_kernel<...> + conv_halo_kernel<...> + gemm_wide_kernel<...> + convws_kernel<...> + lnlin_kernel<...> + xattn_kernel + xchain_kernel, all "
             "instantiations) over 3 eager UNet evaluations at 512^2, batch 3 (tools/pmc_unet.sh: rocprofv3 --pmc FETCH_SIZE and --pmc "
             "WRITE_SIZE in separate passes); also contains the few GEMM launches of context creation",
     "launches": nf, "fetch_kb_raw_sum": fetch, "write_kb_sum": write,
