@@ -146,14 +146,33 @@ static __device__ __forceinline__ double shfl_xor_d(double v, int o) {
   lo = __shfl_xor(lo, o); hi = __shfl_xor(hi, o);
   return __hiloint2double(hi, lo);
 }
+// fp64 sum over aligned groups of 8 lanes, result in all 8 -- three DPP steps (quad_perm xor 1, xor 2, row_half_mirror) instead of three
+// ds_bpermute round trips per word
+template <int CTRL>
+static __device__ __forceinline__ double dpp_add8_d(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ double sum8_d(double v) {
+  v = dpp_add8_d<0xb1>(v);   // quad_perm [1, 0, 3, 2]
+  v = dpp_add8_d<0x4e>(v);   // quad_perm [2, 3, 0, 1]
+  v = dpp_add8_d<0x141>(v);  // row_half_mirror: lane i <- lane 7 - i of its half row (the other quad)
+  return v;
+}
 // (mean, rstd) of a group from its fp64 totals
 static __device__ __forceinline__ void gn_mean_rstd(double s, double q, float inv_count, float eps, float& mean, float& rstd) {
-  // the element count is an integer below 2^24: recovered exactly from its fp32 reciprocal.  (Multiplying by the ROUNDED reciprocal scales
+  // the element count is an integer below 2^22: recovered exactly from its fp32 reciprocal.  (Multiplying by the ROUNDED reciprocal scales
   // E[x^2] and mean^2 by (1 + 6e-8) and (1 + 6e-8)^2: the difference is off by 6e-8 E[x^2] -- 0.5 % of the variance at |mean| = 300 sigma,
-  // which is what the first fp64 version of this function still showed: 1e-2 in the normalised output.)
-  const double n = rint(1.0 / (double)inv_count);
-  const double m = s / n;
-  const double var = q / n - m * m;
+  // which is what the first fp64 version of this function still showed: 1e-2 in the normalised output.)  No fp64 DIVISION here: hipcc expands
+  // one into ~40 instructions and this sits, single-lane, in front of the barrier of every GroupNorm launch (three of them cost a 256^2 stamp
+  // 0.4 ms): the fp64 reciprocal of the count is the fp32 one refined by one Newton step (relative error 4e-15).
+  const float nf = rintf(1.0f / inv_count);
+  const double n = (double)nf;
+  double inv = (double)(1.0f / nf);
+  inv = inv * (2.0 - n * inv);
+  const double m = s * inv;
+  const double var = q * inv - m * m;
   mean = (float)m;
   rstd = rsqrtf(fmaxf((float)var, 0.f) + eps);
 }

@@ -193,8 +193,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const GemmParams p) {
       double s = 0.0, q = 0.0;  // (fp64 totals and variance: common.h sum_pairs_strided_d)
       if (g < groups)
         sum_pairs_strided_d(p.gn_part + ((size_t)img * p.gn_nchunk + j) * groups * 2 + g * 2, (size_t)8 * groups * 2, (p.gn_nchunk - j + 7) / 8, s, q);
-#pragma unroll
-      for (int o = 4; o > 0; o >>= 1) { s += shfl_xor_d(s, o); q += shfl_xor_d(q, o); }
+    s = sum8_d(s); q = sum8_d(q);
       if (g < groups && j == 0) gn_mean_rstd(s, q, 1.0f / ((float)(H * W) * (float)p.gn_cpg), p.gn_eps, gst[2 * g], gst[2 * g + 1]);
     }
     __syncthreads();

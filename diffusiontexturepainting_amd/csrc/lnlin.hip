@@ -142,8 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
       // phase 1 does not touch); published by the k-block barriers below, read once after the loop
       float* const gst = (float*)(smem + 4 * 16384);          // [32][2] mean, rstd
       float* const gtab = gst + 64;                           // [K] a, then [K] d
-#pragma unroll
-      for (int o = 4; o > 0; o >>= 1) { gs += shfl_xor_d(gs, o); gq += shfl_xor_d(gq, o); }
+      gs = sum8_d(gs); gq = sum8_d(gq);
       if ((tid & 7) == 0) gn_mean_rstd(gs, gq, 1.0f / ((float)p.M * (float)p.gn_cpg), p.gn_eps, gst[2 * (tid >> 3)], gst[2 * (tid >> 3) + 1]);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();

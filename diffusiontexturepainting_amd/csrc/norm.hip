@@ -12,10 +12,26 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// fp64 sum over the wave, result in every lane.  Not a butterfly of __shfl_xor (ds_bpermute: an LDS round trip per level and word -- the first
+// fp64 version of the single-launch GroupNorm kernels was 0.6 us per launch slower than the fp32 one, +0.6 % on a 256^2 stamp) but the DPP
+// reduction of the GFX9 family: row_shr 1 / 2 / 4 / 8 inside each row of 16 lanes, row_bcast15 and row_bcast31 across the rows (lanes whose
+// source is outside the row / masked off add the identity), the total lands in lane 63 and is read back through an SGPR.  18 VALU moves + 6 fp64
+// adds, fixed order (deterministic).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_d(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += shfl_xor_d(v, o);
-  return v;
+  v = dpp_add_d<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add_d<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add_d<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add_d<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row's sum
+  v = dpp_add_d<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add_d<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -233,8 +249,7 @@ __global__ __launch_bounds__(1024) void gn_apply_kernel(const f16* __restrict__ 
     double s = 0.0, q = 0.0;
     if (g < groups)  // chunks j, j + 8, ... in order, loads up front; fp64 totals and variance (common.h: sum_pairs_strided_d)
       sum_pairs_strided_d(partial + ((size_t)b * nchunk + j) * groups * 2 + g * 2, (size_t)8 * groups * 2, (nchunk - j + 7) / 8, s, q);
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) { s += shfl_xor_d(s, o); q += shfl_xor_d(q, o); }
+    s = sum8_d(s); q = sum8_d(q);
     if (g < groups && j == 0) gn_mean_rstd(s, q, inv_count, eps, st[g * 2], st[g * 2 + 1]);
     if (groups > 32) {  // second half of the groups (not used on this path, kept for generality)
       const int g2 = g + 32;
@@ -555,8 +570,7 @@ __global__ __launch_bounds__(256) void gn_fold_weights_kernel(const f16* __restr
     double s = 0.0, q = 0.0;
     if (g < groups)  // chunks j, j + 8, ... in order, loads up front; fp64 totals and variance (common.h: sum_pairs_strided_d)
       sum_pairs_strided_d(partial + ((size_t)b * nchunk + j) * groups * 2 + g * 2, (size_t)8 * groups * 2, (nchunk - j + 7) / 8, s, q);
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) { s += shfl_xor_d(s, o); q += shfl_xor_d(q, o); }
+    s = sum8_d(s); q = sum8_d(q);
     if (g < groups && j == 0) gn_mean_rstd(s, q, inv_count, eps, st[g * 2], st[g * 2 + 1]);
   }
   __syncthreads();
