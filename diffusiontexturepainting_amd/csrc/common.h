@@ -146,6 +146,47 @@ static __device__ __forceinline__ double shfl_xor_d(double v, int o) {
   lo = __shfl_xor(lo, o); hi = __shfl_xor(hi, o);
   return __hiloint2double(hi, lo);
 }
+// ---- all-reduce over aligned groups of W lanes WITHOUT the LDS: __shfl_xor compiles to ds_bpermute_b32 (an LDS round trip per level, and it
+// enters the hand-counted lgkmcnt of the kernels that issue their fragment reads by hand); these are VALU moves.  Levels 1 and 2: DPP quad_perm;
+// 4 and 8: row_half_mirror / row_mirror (every lane of a quad / half row holds the same partial by then, so "the mirrored lane" is a lane of the
+// other quad / half: the same pairs, in the same order, as the xor butterfly taken from the small offsets up); 16 and 32: v_permlane16_swap /
+// v_permlane32_swap of gfx950 (inline asm: this hipcc's builtins return their first result twice, attn_dma.hip).  All lanes of the group must be
+// active.  Bit-identical to `for (o = 1; o < W; o <<= 1) v = op(v, __shfl_xor(v, o))`.
+template <int CTRL>
+static __device__ __forceinline__ float dpp_get_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+static __device__ __forceinline__ void swap16_f(float x, float& a, float& b) {  // a + b = x + x of the lane 16 away (xor 16)
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+static __device__ __forceinline__ void swap32_f(float x, float& a, float& b) {  // a = x of lane (l & 31), b = x of lane (l & 31) + 32
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+template <int W>
+static __device__ __forceinline__ float group_allsum(float v) {
+  static_assert(W == 2 || W == 4 || W == 8 || W == 16 || W == 32 || W == 64, "group width");
+  v += dpp_get_f<0xb1>(v);
+  if constexpr (W >= 4) v += dpp_get_f<0x4e>(v);
+  if constexpr (W >= 8) v += dpp_get_f<0x141>(v);
+  if constexpr (W >= 16) v += dpp_get_f<0x140>(v);
+  if constexpr (W >= 32) { float a, b; swap16_f(v, a, b); v = a + b; }
+  if constexpr (W >= 64) { float a, b; swap32_f(v, a, b); v = a + b; }
+  return v;
+}
+template <int W>
+static __device__ __forceinline__ float group_allmax(float v) {
+  static_assert(W == 2 || W == 4 || W == 8 || W == 16, "group width");
+  v = fmaxf(v, dpp_get_f<0xb1>(v));
+  if constexpr (W >= 4) v = fmaxf(v, dpp_get_f<0x4e>(v));
+  if constexpr (W >= 8) v = fmaxf(v, dpp_get_f<0x141>(v));
+  if constexpr (W >= 16) v = fmaxf(v, dpp_get_f<0x140>(v));
+  return v;
+}
+static __device__ __forceinline__ float xhalf_sum(float v) { float a, b; swap32_f(v, a, b); return a + b; }   // v + v of lane ^ 32
+static __device__ __forceinline__ float xhalf_max(float v) { float a, b; swap32_f(v, a, b); return fmaxf(a, b); }
+
 // fp64 sum over aligned groups of 8 lanes, result in all 8 -- three DPP steps (quad_perm xor 1, xor 2, row_half_mirror) instead of three
 // ds_bpermute round trips per word
 template <int CTRL>

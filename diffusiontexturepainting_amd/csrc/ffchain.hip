@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void ffchain_kernel(const FfchainParams p) {
         s1 = __builtin_amdgcn_fdot2(v, one2, s1, false);
         s2 = __builtin_amdgcn_fdot2(v, v, s2, false);
       }
-    s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 32);
+    s1 = xhalf_sum(s1);
+    s2 = xhalf_sum(s2);
     mean = s1 * (1.0f / K);
     rstd = rsqrtf(fmaxf(s2 * (1.0f / K) - mean * mean, 0.f) + p.ln_eps);
   }

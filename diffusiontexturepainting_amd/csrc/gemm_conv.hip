@@ -330,8 +330,7 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
           for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 += f * f; }
         }
       }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      s1 = group_allsum<16>(s1); s2 = group_allsum<16>(s2);  // (DPP, common.h: no LDS round trips)
       if (l16 == 0) {
         const float mean = s1 / (float)p.K;
         const float var = fmaxf(s2 / (float)p.K - mean * mean, 0.f);
@@ -592,11 +591,11 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
         float mx = -3.0e38f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) if (half + e < p.sm_valid) mx = fmaxf(mx, x[e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = group_allmax<2>(mx);
         float sum = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { x[e] = (half + e < p.sm_valid) ? __expf(x[e] - mx) : 0.f; sum += x[e]; }
-        sum += __shfl_xor(sum, 1);
+        sum = group_allsum<2>(sum);
         const float inv = 1.0f / sum;
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] *= inv;
@@ -630,8 +629,7 @@ __global__ __launch_bounds__(256 * KH + 64 * LW) void gemm_kernel(const GemmPara
       }
     }
     if (fl & GF_ROWSTATS) {  // NC consecutive lanes hold one row of this N tile: fixed-order shuffle reduce
-#pragma unroll
-      for (int o = NC / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      s1 = group_allsum<NC>(s1); s2 = group_allsum<NC>(s2);
       if (nc == 0 && m < p.M) {
         p.st_out[((size_t)tile_n * st_rows + st_m0 + m) * 2] = s1;
         p.st_out[((size_t)tile_n * st_rows + st_m0 + m) * 2 + 1] = s2;
@@ -723,8 +721,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const GemmParam
     const float f = (float)h;
     s1 += f; s2 += f * f;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  s1 = group_allsum<64>(s1); s2 = group_allsum<64>(s2);
   if (lane == 0) { p.st_out[(size_t)m * 2] = s1; p.st_out[(size_t)m * 2 + 1] = s2; }
 }
 

@@ -202,8 +202,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_wide_kernel(const GemmParams
           for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1 += f; s2 += f * f; }
         }
       }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      s1 = group_allsum<16>(s1); s2 = group_allsum<16>(s2);
       if (l16 == 0) {
         const float mean = s1 / (float)p.K;
         rowst[2 * r] = mean;
@@ -413,8 +412,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_wide_kernel(const GemmParams
       }
       if constexpr (NTE == NT && (NC & (NC - 1)) == 0 && NC <= 64) {
         if (fl & GF_ROWSTATS) {  // NC consecutive lanes hold one row of this N tile: fixed-order shuffle reduce
-#pragma unroll
-          for (int o = NC / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+          s1 = group_allsum<NC>(s1); s2 = group_allsum<NC>(s2);
           if (nc == 0 && ml < ROWS_EP && m < p.M) {
             p.st_out[((size_t)tile_n * st_rows + m) * 2] = s1;
             p.st_out[((size_t)tile_n * st_rows + m) * 2 + 1] = s2;

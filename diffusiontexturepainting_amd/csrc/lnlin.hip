@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         s2 = __builtin_amdgcn_fdot2(v, v, s2, false);
       }
     }
-    s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 32);
+    s1 = xhalf_sum(s1);
+    s2 = xhalf_sum(s2);
     mean = s1 * (1.0f / K);
     rstd = rsqrtf(fmaxf(s2 * (1.0f / K) - mean * mean, 0.f) + p.ln_eps);
   }
@@ -371,8 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float f = (float)ov[e]; s1 += f; s2 += f * f; }
-            s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
-            s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+            s1 = group_allsum<4>(s1); s2 = group_allsum<4>(s2);
             rs1[rr] += s1; rs2[rr] += s2;
           }
         }

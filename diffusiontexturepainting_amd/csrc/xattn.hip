@@ -236,11 +236,11 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
       float mx = -3.0e38f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) if (half + e < p.sm_valid) mx = fmaxf(mx, x[e]);
-      mx = fmaxf(mx, __shfl_xor(mx, 1));
+      mx = group_allmax<2>(mx);
       float sum = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { x[e] = (half + e < p.sm_valid) ? __expf(x[e] - mx) : 0.f; sum += x[e]; }
-      sum += __shfl_xor(sum, 1);
+      sum = group_allsum<2>(sum);
       const float inv = 1.0f / sum;
       f16x8 o;
 #pragma unroll
@@ -314,8 +314,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnParams p) {
         *(f16x8*)(p.Y + (row0 + m) * p.ldy + n) = o;
       }
       if (p.st_out) {  // NC consecutive lanes hold one row of this column tile: fixed-order shuffle reduce
-#pragma unroll
-        for (int o = NC / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        s1 = group_allsum<NC>(s1); s2 = group_allsum<NC>(s2);
         if (nc == 0 && m < p.S) {
           p.st_out[((size_t)ct * p.st_rows + row0 + m) * 2] = s1;
           p.st_out[((size_t)ct * p.st_rows + row0 + m) * 2 + 1] = s2;

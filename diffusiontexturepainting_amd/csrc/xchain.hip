@@ -18,7 +18,7 @@
 //     two ds_read_b64: no re-packed weights;
 //   * out1's 32-column chunks become y2 fragments (+ bias + residual, rounded to fp16: y2 never exists in memory), the LayerNorm-2
 //     statistics are per-LANE sums over those registers, the score tile of a 16-column head group sits in 8 registers of the lane and 8 of
-//     lane ^ 32 (softmax = register math + one __shfl_xor 32 per reduction), P becomes the B fragments of the value-output product, whose
+//     lane ^ 32 (softmax = register math + one v_permlane32_swap per reduction), P becomes the B fragments of the value-output product, whose
 //     residual operand (y2) is still in registers;
 //   * weights stream through the same 3-deep ring of 32-row units as in lnlin.hip (one barrier and 20 / 8 MFMAs per wave and unit, the
 //     pieces of unit u + 2 issued under the MFMAs of unit u), across the three phases without draining: 10 units of Wo, 4 of W1, 10 of W2.
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256) void xchain_kernel(const XchainParams p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) yr[q] = yrn[q];
   }
-  s1 += __shfl_xor(s1, 32);
-  s2 += __shfl_xor(s2, 32);
+  s1 = xhalf_sum(s1);
+  s2 = xhalf_sum(s2);
   const float mean = s1 * (1.0f / K);
   const float rstd = rsqrtf(fmaxf(s2 * (1.0f / K) - mean * mean, 0.f) + p.ln_eps);
 
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void xchain_kernel(const XchainParams p) {
         const int j = 8 * (r >> 2) + 4 * half + (r & 3);
         if (j < p.sm_valid) mx = fmaxf(mx, x[8 * g + r]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = xhalf_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void xchain_kernel(const XchainParams p) {
         const float e = (j < p.sm_valid) ? __expf(x[8 * g + r] - mx) : 0.f;
         x[8 * g + r] = e; sum += e;
       }
-      sum += __shfl_xor(sum, 32);
+      sum = xhalf_sum(sum);
       const float inv = 1.0f / sum;
       f16x8 o;
 #pragma unroll
@@ -348,8 +348,8 @@ __global__ __launch_bounds__(256) void xchain_kernel(const XchainParams p) {
     }
   }
   if (p.st_out) {
-    r1 += __shfl_xor(r1, 32);
-    r2 += __shfl_xor(r2, 32);
+    r1 = xhalf_sum(r1);
+    r2 = xhalf_sum(r2);
     if (half == 0 && mg < Mtot) { p.st_out[(size_t)mg * 2] = r1; p.st_out[(size_t)mg * 2 + 1] = r2; }
   }
 }
