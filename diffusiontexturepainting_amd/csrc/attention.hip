@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * NW, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 
     float mloc = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, sacc[0][r]), sacc[1][r]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    mloc = xhalf_max(mloc);  // (v_permlane32_swap: no LDS round trip in the tile loop)
     f16x8 pf[2][2];
     float lsum = 0.f;
     if constexpr (SHIFT) {
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * NW, (OCC4 ? 4 : (DP <= 64 ? 3 : (DP <= 80 ? 2 
           for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
         m_run = m_new;
       }
-      if (!ONES) l_run += lsum + __shfl_xor(lsum, 32);
+      if (!ONES) l_run += xhalf_sum(lsum);
     }
     if (p.prio & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
