@@ -21,8 +21,10 @@ timeout 600 python bench.py --batch 8 --steps 3 --warmup 1 --no-cpu-baseline --n
 timeout 600 python bench.py --res 256 --no-cpu-baseline --no-extras > gpurun_out/r06_256.log 2>gpurun_out/r06_256.err
 DTP_BENCH_BACKEND=gloo DTP_BENCH_SAME_DEVICE=1 timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-profile > gpurun_out/r06_gpus2_same_device.log 2>gpurun_out/r06_gpus2_same_device.err
 DTP_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-profile > gpurun_out/r06_rccl_one_rank.log 2>gpurun_out/r06_rccl_one_rank.err
+if [ -z "$DTP_REFRESH_SKIP_ORACLE" ]; then  # (the two long CPU-oracle legs: configs[0] in full on the host, configs[1] + configs[2] at full size -- the GPU suite below repeats the latter)
 timeout 600 python bench.py --cpu-config0 > gpurun_out/r06_cpu_config0.json 2>gpurun_out/r06_cpu_config0.err
 DTP_FULLSIZE_JSON=gpurun_out/r06_fullsize_parity.json timeout 900 python -m pytest tests/test_gpu_fullsize.py -q -x -k test_config1_and_config2_512_20steps_match_cpu_oracle > gpurun_out/r06_fullsize_parity.log 2>&1
+fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r06 -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-extras > /root/repo/gpurun_out/r06_prof.log 2>&1
@@ -35,7 +37,13 @@ cd /tmp && rm -rf /tmp/profm
 timeout 600 rocprofv3 --marker-trace --stats --output-format csv -d /tmp/profm -o r06 -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras > /root/repo/gpurun_out/r06_prof_marker.log 2>&1
 find /tmp/profm -name "*marker*stats*" -exec cp {} /root/repo/gpurun_out/r06_marker_stats.csv \;
 cd /root/repo
-( time timeout 1500 python -m pytest tests -q -m gpu --durations=15 -x ) > gpurun_out/r06_gpu_suite.log 2>&1
+if [ -n "$DTP_REFRESH_AB" ]; then  # same-box A/B against a reference library (e.g. tools/ab/libdtp_r05.so = round 5 rebuilt from git), shipped tune table on both arms
+  rm -f gpurun_out/ab_summary.log
+  cp diffusiontexturepainting_amd/tune_seed.txt /tmp/ab_tc.txt
+  DTP_TUNE_CACHE=/tmp/ab_tc.txt bash tools/ab.sh $DTP_REFRESH_AB all 2 > /dev/null 2>&1
+  cp gpurun_out/ab_summary.log gpurun_out/r06_ab_r05_vs_r06_final.txt
+fi
+( time DTP_FULLSIZE_JSON=gpurun_out/r06_fullsize_parity.json timeout 1500 python -m pytest tests -q -m gpu --durations=15 -x ) > gpurun_out/r06_gpu_suite.log 2>&1
 tail -3 gpurun_out/r06_gpu_suite.log
 cp /tmp/tc.txt gpurun_out/r06_tune_cache.txt
 for f in b1 b8 256; do grep "^{" gpurun_out/r06_$f.log | tail -1 | grep -o "\"ms_per_step\": [0-9.]*"; done
