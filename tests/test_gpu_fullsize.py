@@ -138,17 +138,24 @@ def test_config4_256_8steps_fp8(weights):
     canvas, brush, cond, uncond, lat, eps = _inputs(1, 256, 400)
     st = dict(steps=8, context_pad=150, tg_steps=8, cfg_weight=2.0, tg_weight=1.0)
     ref = pipeline.generate_raw(weights[1], brush, cond, uncond, canvas, lat, eps, **st)
-    errs = {}
+    errs, outs = {}, {}
     for fp8 in ("full", "attention", False):
         m = MI355ConditionalInpainter(256, device=0, weights=weights[0], max_batch=1, fp8_attention=bool(fp8), fp8_linear=(fp8 == "full"))
         m.set_conditioning(cond, uncond, brush)
         got = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
         torch.cuda.synchronize()
-        errs[fp8] = (got.cpu() - ref).abs().max().item()
-        print(f"256^2 / 8 steps, fp8 attention + linear={fp8}: max abs pixel error {errs[fp8]:.2e}, stage ms {m.stage_times_ms()}")
+        outs[fp8] = got.cpu()
+        errs[fp8] = (outs[fp8] - ref).abs().max().item()
+        print(f"256^2 / 8 steps, fp8 attention + linear={fp8}: max abs pixel error {errs[fp8]:.2e}, mean {(outs[fp8] - ref).abs().mean().item():.2e}, "
+              f"stage ms {m.stage_times_ms()}")
         assert torch.isfinite(got).all() and m.stamp_info()["unet_evals"] == 7
     assert errs[False] <= 1e-2 and errs["attention"] <= FP8_ATTN_PIXEL_TOL and errs["full"] <= FP8_FULL_PIXEL_TOL
-    assert len({errs[False], errs["attention"], errs["full"]}) == 3  # the options really switched the kernels
+    # the options really switched the kernels: the three images differ.  (Rounds 4-5 compared the three MAXIMA; since the GroupNorm sums
+    # changed their order in round 6 the largest error of this stamp sits on a pixel of the KNOWN region -- re-imposed latents through the
+    # VAE decoder, the same 2.71e-3 whatever the UNet computes in -- so the maxima coincide while the images do not.)
+    d_attn, d_full = (outs["attention"] - outs[False]).abs().max().item(), (outs["full"] - outs["attention"]).abs().max().item()
+    print(f"fp8 attention vs fp16: {d_attn:.2e}; + fp8 Linears vs fp8 attention: {d_full:.2e}")
+    assert d_attn > 0 and d_full > 0
 
 FP8_TRAINED_LIKE_TOL = 1e-2  # fp8 attention + Linears with CALIBRATED activation scales on the trained-like weight set (measured 5.4e-3)
 
