@@ -5,8 +5,11 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffusiontexturepainting_amd import ops
 
-shapes = [(3, 4096, 320), (3, 4096, 640), (3, 4096, 960), (3, 1024, 1920), (3, 1024, 640), (2, 4096, 320), (1, 4096, 512), (1, 65536, 256)]
-tag = "two-launch" if os.environ.get("DTP_NO_GN_GRID") == "1" else "grid mode " + os.environ.get("DTP_GN_GRID_MODE", "0")
+shapes = [(3, 4096, 320), (3, 4096, 640), (3, 4096, 960), (3, 1024, 1920), (3, 1024, 1280), (3, 1024, 960), (3, 1024, 640), (1, 4096, 512), (1, 65536, 256),
+          (24, 4096, 320), (24, 4096, 640), (24, 4096, 960), (24, 1024, 1920), (24, 1024, 1280), (24, 1024, 640)]
+if os.environ.get("GN_SHAPES") == "small":
+    shapes = shapes[:9]
+tag = "fused_kb=" + os.environ.get("DTP_GN_FUSED_KB", "0") if "DTP_GN_FUSED_KB" in os.environ else ("two-launch" if os.environ.get("DTP_NO_GN_GRID") == "1" else "grid mode " + os.environ.get("DTP_GN_GRID_MODE", "0"))
 out = []
 for b, hw, c in shapes:
     x = (torch.randn(b, hw, c) * 1.5 + 0.3).half().cuda()
