@@ -24,10 +24,11 @@ import sys
 import tempfile
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import diffusiontexturepainting_amd  # noqa: E402,F401  (first: with $DTP_RUNTIME_ENV=1 it sets the optional HIP runtime configuration before torch loads the runtime)
+
+import torch  # noqa: E402
 
 PEAK_MFMA_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0

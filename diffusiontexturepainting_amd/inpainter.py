@@ -51,6 +51,8 @@ class MI355ConditionalInpainter(ConditionalInpainterBase):
             weights = dict(unet=W.synthetic_unet(), lora=W.synthetic_lora(), vae=W.synthetic_vae(),
                            clip=W.synthetic_clip(), penc=W.synthetic_patch_encoder())
         self._load(weights)
+        if not use_graph or os.environ.get("DTP_NO_GRAPH", "0") not in ("", "0"):  # eager launches instead of hipGraph replay (A/B, debugging)
+            check(self._lib.dtp_set_option(self._h, b"use_graph", 0), "dtp_set_option(use_graph)")
         if fp8_attention is None:
             fp8_attention = os.environ.get("DTP_FP8", "0") not in ("", "0")
         self.fp8_attention = bool(fp8_attention)

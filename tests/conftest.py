@@ -6,6 +6,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import diffusiontexturepainting_amd  # noqa: E402,F401  (with $DTP_RUNTIME_ENV=1: the optional HIP runtime configuration, before any test imports torch)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

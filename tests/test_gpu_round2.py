@@ -238,6 +238,26 @@ def test_check_finite_option(env):
     assert torch.equal(again, out)
 
 
+def test_eager_launches_match_graph_replay_bit_for_bit():
+    """`use_graph=False` (the constructor argument was accepted and ignored until round 6; $DTP_NO_GRAPH=1 does the same): the stamp as plain
+    stream launches -- the A/B arm of profiles/r06_graph_vs_eager.txt -- is the SAME stamp, bit for bit, as the captured graph's replay."""
+    from diffusiontexturepainting_amd import weights as W
+    from diffusiontexturepainting_amd.inpainter import MI355ConditionalInpainter
+    sd = dict(unet=W.synthetic_unet(2), lora=W.synthetic_lora(2), vae=W.synthetic_vae(2))
+    canvas, brush, cond, uncond, lat, eps = _inputs(2, R, 910)
+    st = dict(steps=4, context_pad=20, tg_steps=2, cfg_weight=2.0, tg_weight=1.0)
+    outs = []
+    for graph in (True, False):
+        m = MI355ConditionalInpainter(R, device=0, weights=sd, max_batch=2, use_graph=graph)
+        m.set_conditioning(cond, uncond, brush)
+        for _ in range(2):  # (the first call captures; the second replays)
+            y = m.generate_raw(canvas, latents=lat, vae_eps=eps, **st)
+        torch.cuda.synchronize()
+        outs.append(y.cpu())
+        del m
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
 def test_stamp_enqueue_does_not_block_the_host():
     """dtp_stamp only enqueues (include/dtp.h): two back-to-back stamps return to the host long before the device is done."""
     from diffusiontexturepainting_amd import weights as W
